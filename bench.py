@@ -1,0 +1,166 @@
+#!/usr/bin/env python
+"""Headline benchmark: examples/sec of sync-replica data-parallel training of the
+MNIST-shaped MLP (784 -> 128 relu -> dropout .3 -> 128 relu -> dropout .3 -> 10 softmax,
+Adam, softmax cross-entropy) in fp32 on N MI355X GPUs of one node.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        --master-port 29500 bench.py --gpus 8 --steps 50 --warmup 10
+
+Every timed step is a complete training step on fresh device-resident synthetic data:
+forward, loss, backward, gradient reduce-scatter, sharded Adam apply, parameter
+all-gather, global_step increment.  Weak scaling: the per-GPU batch is fixed.
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# CPU proxy of the reference workload measured for BASELINE.md (examples/s, 1 thread, PyTorch CPU)
+BASELINE_EXAMPLES_PER_SEC = 37700.0
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--model", default="mnist_mlp", choices=["mnist_mlp", "xor_mlp", "mnist_cnn", "wide_mlp"])
+    ap.add_argument("--batch-per-gpu", type=int, default=0, help="0 = the model's default")
+    ap.add_argument("--pool", type=int, default=4, help="distinct device-resident synthetic batches cycled through")
+    ap.add_argument("--graph", type=int, default=-1, help="replay the step from a hipGraph (-1 = auto: single GPU only)")
+    ap.add_argument("--bucket-mb", type=float, default=64.0)
+    ap.add_argument("--width", type=int, default=16384, help="wide_mlp hidden width")
+    ap.add_argument("--depth", type=int, default=5, help="wide_mlp hidden depth")
+    ap.add_argument("--eval", type=int, default=0, help="also train for this many extra steps and report test accuracy")
+    return ap.parse_args()
+
+
+DEFAULT_BATCH = {"mnist_mlp": 32768, "xor_mlp": 32768, "mnist_cnn": 1024, "wide_mlp": 2048}
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    from distributed_tensorflow_amd import data, models
+    from distributed_tensorflow_amd.ops import _native
+    from distributed_tensorflow_amd.parallel import Communicator, SyncReplicasStrategy, init_process_group
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU")
+    dev = torch.device("cuda", local_rank % torch.cuda.device_count())
+    torch.cuda.set_device(dev)
+    _native.kernels()  # fail loudly if the HIP library is missing
+
+    strategy = None
+    if world > 1:
+        init_process_group("nccl", device=dev)
+        strategy = SyncReplicasStrategy(Communicator(), bucket_bytes=int(args.bucket_mb * (1 << 20)))
+
+    B = args.batch_per_gpu or DEFAULT_BATCH[args.model]
+    if args.model == "mnist_mlp":
+        model = models.mnist_mlp()
+        loss = "sparse_categorical_crossentropy"
+        make = lambda n, seed: data.mnist_like(n, seed=seed, device=dev)
+    elif args.model == "xor_mlp":
+        model = models.xor_mlp()
+        loss = "mean_squared_error"
+        make = lambda n, seed: data.get_data(n, val_set_size=0, seed=seed, device=dev)[:2]
+    elif args.model == "mnist_cnn":
+        model = models.mnist_cnn()
+        loss = "sparse_categorical_crossentropy"
+        def make(n, seed):
+            x, y = data.mnist_like(n, seed=seed, device=dev)
+            return x.view(n, 28, 28, 1), y
+    else:
+        model = models.wide_mlp(width=args.width, depth=args.depth)
+        loss = "sparse_categorical_crossentropy"
+        make = lambda n, seed: data.mnist_like(n, seed=seed, device=dev)
+    model.compile(loss=loss, optimizer="adam", metrics=["accuracy"], strategy=strategy, device=dev, seed=0)
+
+    pool = max(1, args.pool)
+    x_all, y_all = make(B * pool, 1000 + rank)
+    batches = [(x_all[i * B:(i + 1) * B], y_all[i * B:(i + 1) * B]) for i in range(pool)]
+
+    use_graph = (args.graph == 1) or (args.graph == -1 and world == 1)
+    graphs = None
+    if use_graph:
+        graphs = [model._graphed_steps(bx, by, B, 1) for bx, by in batches]
+
+    def step(i):
+        if graphs is not None:
+            graphs[i % pool].replay()
+        else:
+            bx, by = batches[i % pool]
+            model.train_step(bx, by)
+
+    def fence():
+        if world > 1:
+            dist.barrier(device_ids=[dev.index])
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    logs = model.read_stats()
+    test_acc = None
+    if args.eval > 0:
+        for i in range(args.eval):
+            step(i)
+        xt, yt = make(8192, 99)
+        test_acc = model.evaluate(xt, yt, batch_size=8192)[1]
+
+    global_batch = B * world
+    value = global_batch * args.steps / elapsed
+    if rank == 0:
+        out = {
+            "metric": "examples/sec (whole node) sync-DP MNIST-shape model",
+            "value": value,
+            "unit": "examples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1000.0 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": value / BASELINE_EXAMPLES_PER_SEC,
+            "dtype": "fp32",
+            "data": "synthetic (device-resident MNIST-shaped inputs, random-init weights)",
+            "config": {"model": args.model, "global_batch": global_batch, "batch_per_gpu": B, "seq_len": None,
+                       "parallelism": "dp%d" % world, "params": model.store.num_params,
+                       "optimizer": "adam", "hip_graph": bool(use_graph),
+                       "train_loss": logs.get("loss"), "train_acc": logs.get("acc"), "test_acc": test_acc},
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier(device_ids=[dev.index])
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

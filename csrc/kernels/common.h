@@ -1,0 +1,53 @@
+// Shared device helpers for the gfx950 (CDNA4, wave64) kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define DTF_API extern "C" __attribute__((visibility("default")))
+
+// Activation codes shared with the Python side (ops/_native.py).
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2 };
+
+#define DTF_CHECK_LAUNCH()                               \
+    do {                                                 \
+        hipError_t e__ = hipGetLastError();              \
+        if (e__ != hipSuccess) return (int)e__;          \
+    } while (0)
+
+// 32-bit finaliser with full avalanche ("lowbias32").
+__device__ __forceinline__ uint32_t dtf_mix32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7feb352dU;
+    x ^= x >> 15;
+    x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+
+// Per-launch dropout key: one value per (layer seed, training step).  The step
+// lives in device memory so a captured hipGraph draws a fresh mask on every replay.
+__device__ __forceinline__ uint32_t dtf_dropout_key(uint32_t seed, const long long* step_ptr) {
+    unsigned long long s = step_ptr ? (unsigned long long)(*step_ptr) : 0ull;
+    uint32_t k = dtf_mix32((uint32_t)s + 0x9E3779B9u);
+    k = dtf_mix32(k ^ ((uint32_t)(s >> 32) * 0x85ebca6bU) ^ seed);
+    return k;
+}
+
+// Counter-based uniform in [0,1): a pure function of (key, element index), so the
+// backward pass can regenerate a mask instead of storing it.
+__device__ __forceinline__ float dtf_uniform(uint32_t key, unsigned long long idx) {
+    uint32_t r = dtf_mix32((uint32_t)idx * 0x9E3779B1u + key);
+    r = dtf_mix32(r ^ ((uint32_t)(idx >> 32) + 0x632BE5ABu) ^ (key >> 7));
+    return (float)(r >> 8) * (1.0f / 16777216.0f);
+}
+
+__device__ __forceinline__ float dtf_sigmoid(float z) { return 1.0f / (1.0f + __expf(-z)); }
+
+__device__ __forceinline__ float dtf_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}

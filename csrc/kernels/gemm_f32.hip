@@ -1,0 +1,371 @@
+// Exact-fp32 dense-layer GEMMs for gfx950 on v_mfma_f32_32x32x2_f32 (wave64 MFMA).
+//
+// One templated LDS-tiled kernel serves the three products a dense layer needs
+// (what TF runs as MatMul / BiasAdd / Relu / Sigmoid / dropout and their gradients
+// behind /root/reference/example.py:150-154 and :170):
+//
+//   forward   Y[M,N]  = dropout(act(X[M,K] . W[K,N] + b))          A k-contig, B n-contig
+//   dgrad     dX[M,K] = (dZ[M,N] . W[K,N]^T) * act'(Yprev)         A k-contig, B k-contig
+//   wgrad     dW[K,N] = X[M,K]^T . dZ[M,N],  db[N] = colsum(dZ)     A m-contig, B n-contig
+//
+// Block = 256 threads = 4 waves; each wave owns a TMxTN grid of 32x32 MFMA tiles.
+// K is consumed in 32-deep LDS tiles.  Inside each group of 8 k-values the lane half
+// h = lane>>5 takes k = 8*kk + 4*h + t at MFMA step t: a GEMM sums over k in any
+// order, and this order lets a k-contiguous operand be fetched with one 16-byte
+// ds_read_b128 per four MFMAs.  Row stride of k-contiguous LDS tiles is 36 floats
+// (144 B = 9 x 16 B, odd multiple), which makes those b128 reads conflict-free.
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LDK = BK + 4;  // row stride (floats) of a k-contiguous LDS tile
+
+enum { EPI_FWD = 0, EPI_DX = 1, EPI_DW = 2 };
+
+struct GemmArgs {
+    const float* A;
+    const float* B;
+    float* C;
+    int lda, ldb, ldc;
+    int M, N, K;
+    int k_chunk;              // K range handled by one blockIdx.z (multiple of BK)
+    long long c_split_stride; // elements between successive split slabs of C
+    // forward epilogue
+    const float* bias;
+    int act;
+    float keep;               // dropout keep probability; >= 1 disables dropout
+    uint32_t seed;
+    const long long* step_ptr;
+    // dgrad epilogue
+    const float* yprev;       // output of the producing layer (post activation/dropout)
+    int ldy;
+    float scale_prev;         // 1/keep of the producing layer's dropout (1 if none)
+    // wgrad extras
+    float* colsum;            // [splits][N] partial bias gradients (may be null)
+};
+
+template <int ROWS, bool KC>
+struct TileLoader {
+    // Tile of ROWS (M- or N-dim) x BK (k-dim).  KC: k is the contiguous global dim.
+    static constexpr int NV = ROWS * BK / 4 / 256;
+    static constexpr int LD = KC ? LDK : (ROWS + 4);
+    static constexpr int LDS_FLOATS = KC ? ROWS * LDK : BK * (ROWS + 4);
+
+    f32x4 v[NV];
+
+    __device__ __forceinline__ void load(const float* __restrict__ base, int ld, int mn0, int mn_dim,
+                                         int k0, int k_end, bool vec_ok, int tid) {
+#pragma unroll
+        for (int s = 0; s < NV; ++s) {
+            const int id = tid + 256 * s;
+            int r, c;  // r: index along mn, c: index along k (both tile-local)
+            if (KC) {
+                r = id >> 3;
+                c = (id & 7) * 4;
+            } else {
+                c = id / (ROWS / 4);
+                r = (id % (ROWS / 4)) * 4;
+            }
+            const int gm = mn0 + r, gk = k0 + c;
+            f32x4 x = {0.f, 0.f, 0.f, 0.f};
+            if (KC) {
+                if (gm < mn_dim) {
+                    const float* p = base + (long long)gm * ld + gk;
+                    if (vec_ok && gk + 3 < k_end) {
+                        x = *reinterpret_cast<const f32x4*>(p);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (gk + j < k_end) x[j] = p[j];
+                    }
+                }
+            } else {
+                if (gk < k_end) {
+                    const float* p = base + (long long)gk * ld + gm;
+                    if (vec_ok && gm + 3 < mn_dim) {
+                        x = *reinterpret_cast<const f32x4*>(p);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (gm + j < mn_dim) x[j] = p[j];
+                    }
+                }
+            }
+            v[s] = x;
+        }
+    }
+
+    __device__ __forceinline__ void store(float* lds, int tid) const {
+#pragma unroll
+        for (int s = 0; s < NV; ++s) {
+            const int id = tid + 256 * s;
+            int off;
+            if (KC) {
+                off = (id >> 3) * LDK + (id & 7) * 4;
+            } else {
+                off = (id / (ROWS / 4)) * (ROWS + 4) + (id % (ROWS / 4)) * 4;
+            }
+            *reinterpret_cast<f32x4*>(lds + off) = v[s];
+        }
+    }
+};
+
+// Fragment for MFMA steps t=0..3 of k-group kk: element t belongs to k = 8*kk + 4*h + t.
+template <int ROWS, bool KC>
+__device__ __forceinline__ f32x4 read_frag(const float* lds, int mn, int kk, int h) {
+    if (KC) {
+        return *reinterpret_cast<const f32x4*>(lds + mn * LDK + kk * 8 + 4 * h);
+    } else {
+        const float* p = lds + (kk * 8 + 4 * h) * (ROWS + 4) + mn;
+        f32x4 r;
+        r[0] = p[0];
+        r[1] = p[ROWS + 4];
+        r[2] = p[2 * (ROWS + 4)];
+        r[3] = p[3 * (ROWS + 4)];
+        return r;
+    }
+}
+
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
+    static_assert(WM * WN == 4, "block is four waves");
+    constexpr int TM = BM / WM / 32;
+    constexpr int TN = BN / WN / 32;
+    static_assert(TM >= 1 && TN >= 1, "wave tile must hold one 32x32 MFMA tile");
+    using LoadA = TileLoader<BM, A_KC>;
+    using LoadB = TileLoader<BN, B_KC>;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;
+    float* Bs = smem + LoadA::LDS_FLOATS;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, h = lane >> 5;
+
+    const int m0 = blockIdx.y * BM;
+    const int n0 = blockIdx.x * BN;
+    const int kbeg = blockIdx.z * p.k_chunk;
+    const int kend = min(p.K, kbeg + p.k_chunk);
+
+    const bool a_vec = ((p.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.A) & 15) == 0);
+    const bool b_vec = ((p.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.B) & 15) == 0);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float csum = 0.f;  // wgrad: partial bias gradient of column n0 + tid
+    const bool do_colsum = (EPI == EPI_DW) && (p.colsum != nullptr) && (blockIdx.y == 0);
+
+    LoadA la;
+    LoadB lb;
+    la.load(p.A, p.lda, m0, p.M, kbeg, kend, a_vec, tid);
+    lb.load(p.B, p.ldb, n0, p.N, kbeg, kend, b_vec, tid);
+    la.store(As, tid);
+    lb.store(Bs, tid);
+    __syncthreads();
+
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        const bool more = (k0 + BK) < kend;
+        if (more) {
+            la.load(p.A, p.lda, m0, p.M, k0 + BK, kend, a_vec, tid);
+            lb.load(p.B, p.ldb, n0, p.N, k0 + BK, kend, b_vec, tid);
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            f32x4 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = read_frag<BM, A_KC>(As, (wm * TM + i) * 32 + li, kk, h);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = read_frag<BN, B_KC>(Bs, (wn * TN + j) * 32 + li, kk, h);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
+        }
+        if (EPI == EPI_DW) {
+            if (do_colsum && tid < BN) {
+                // B tile is n-contiguous here: Bs[k][n].  Rows past kend were staged as zeros.
+#pragma unroll 8
+                for (int k = 0; k < BK; ++k) csum += Bs[k * (BN + 4) + tid];
+            }
+        }
+        __syncthreads();
+        if (more) {
+            la.store(As, tid);
+            lb.store(Bs, tid);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    float* C = p.C + (long long)blockIdx.z * p.c_split_stride;
+    uint32_t key = 0;
+    const bool drop = (EPI == EPI_FWD) && (p.keep < 1.0f);
+    float inv_keep = 1.0f;
+    if (drop) {
+        key = dtf_dropout_key(p.seed, p.step_ptr);
+        inv_keep = 1.0f / p.keep;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + (wn * TN + j) * 32 + li;
+            if (col >= p.N) continue;
+            float bv = 0.f;
+            if (EPI == EPI_FWD && p.bias) bv = p.bias[col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row >= p.M) continue;
+                float v = acc[i][j][r];
+                if (EPI == EPI_FWD) {
+                    v += bv;
+                    if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
+                    else if (p.act == ACT_SIGMOID) v = dtf_sigmoid(v);
+                    if (drop) {
+                        const float u = dtf_uniform(key, (unsigned long long)row * (unsigned)p.N + col);
+                        v = (u < p.keep) ? v * inv_keep : 0.f;
+                    }
+                } else if (EPI == EPI_DX) {
+                    if (p.yprev) {
+                        const float y = p.yprev[(long long)row * p.ldy + col];
+                        if (p.act == ACT_RELU) v = (y > 0.f) ? v * p.scale_prev : 0.f;
+                        else if (p.act == ACT_SIGMOID) v = v * y * (1.0f - y);
+                    }
+                }
+                C[(long long)row * p.ldc + col] = v;
+            }
+        }
+    }
+    if (EPI == EPI_DW) {
+        if (do_colsum && tid < BN && (n0 + tid) < p.N)
+            p.colsum[(long long)blockIdx.z * p.N + n0 + tid] = csum;
+    }
+}
+
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int EPI>
+int launch_cfg(const GemmArgs& a, int splits, hipStream_t s) {
+    using LoadA = TileLoader<BM, A_KC>;
+    using LoadB = TileLoader<BN, B_KC>;
+    const size_t lds = (LoadA::LDS_FLOATS + LoadB::LDS_FLOATS) * sizeof(float);
+    dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, splits);
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, A_KC, B_KC, EPI>), grid, dim3(256), lds, s, a);
+    DTF_CHECK_LAUNCH();
+    return 0;
+}
+
+// Tile choice: the largest tile that still gives every CU a block; N <= 32 uses the
+// narrow tile so thin output layers (10 / 32 columns) do not pay for 128 columns.
+template <bool A_KC, bool B_KC, int EPI>
+int launch_gemm(const GemmArgs& a, int splits, hipStream_t s) {
+    const long long blocks128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128) * splits;
+    if (a.N <= 32) {
+        return launch_cfg<128, 32, 4, 1, A_KC, B_KC, EPI>(a, splits, s);
+    }
+    if (a.N <= 64 || a.M <= 64 || blocks128 < 192) {
+        return launch_cfg<64, 64, 2, 2, A_KC, B_KC, EPI>(a, splits, s);
+    }
+    return launch_cfg<128, 128, 2, 2, A_KC, B_KC, EPI>(a, splits, s);
+}
+
+__global__ void reduce_slabs_kernel(const float* __restrict__ slabs, long long slab_stride, int splits,
+                                    float* __restrict__ out, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += slabs[k * slab_stride + i];
+        out[i] = s;
+    }
+}
+
+}  // namespace
+
+// Y = dropout(act(X.W + b)).  keep >= 1 disables dropout.
+DTF_API int dtf_dense_fwd(const float* X, const float* W, const float* bias, float* Y, int M, int N, int K,
+                          int act, float keep, uint32_t seed, const long long* step_ptr,
+                          hipStream_t stream) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    GemmArgs a = {};
+    a.A = X; a.lda = K;
+    a.B = W; a.ldb = N;
+    a.C = Y; a.ldc = N;
+    a.M = M; a.N = N; a.K = K;
+    a.k_chunk = ((K + BK - 1) / BK) * BK;
+    a.bias = bias; a.act = act; a.keep = keep; a.seed = seed; a.step_ptr = step_ptr;
+    return launch_gemm<true, false, EPI_FWD>(a, 1, stream);
+}
+
+// dX[M,K] = dZ[M,N] . W[K,N]^T, then (optionally) the producing layer's activation and
+// dropout gradient: relu -> (Yprev > 0) * scale_prev, sigmoid -> Yprev (1 - Yprev).
+DTF_API int dtf_dense_bwd_dx(const float* dZ, const float* W, float* dX, int M, int N, int K,
+                             const float* Yprev, int act_prev, float scale_prev, hipStream_t stream) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    GemmArgs a = {};
+    a.A = dZ; a.lda = N;
+    a.B = W; a.ldb = N;       // B(k=n, col=kin) = W[kin*N + n]  -> k-contiguous
+    a.C = dX; a.ldc = K;
+    a.M = M; a.N = K; a.K = N;
+    a.k_chunk = ((N + BK - 1) / BK) * BK;
+    a.yprev = Yprev; a.ldy = K; a.act = act_prev; a.scale_prev = scale_prev;
+    return launch_gemm<true, true, EPI_DX>(a, 1, stream);
+}
+
+// Number of batch splits the wgrad kernel uses for (M,N,K); the workspace must hold
+// splits * (K*N + N) floats when splits > 1.
+DTF_API int dtf_dense_bwd_dw_splits(int M, int N, int K) {
+    const int tiles = (N <= 32) ? ((K + 127) / 128) * ((N + 31) / 32)
+                                : ((K + 127) / 128) * ((N + 127) / 128);
+    int want = (512 + tiles - 1) / tiles;           // ~2 blocks per CU
+    int max_by_m = (M + 4 * BK - 1) / (4 * BK);      // at least 128 rows of batch per split
+    int s = want < max_by_m ? want : max_by_m;
+    return s < 1 ? 1 : s;
+}
+
+// dW[K,N] = X[M,K]^T . dZ[M,N];  db[N] = sum_m dZ[m,:]  (db may be null).
+DTF_API int dtf_dense_bwd_dw(const float* X, const float* dZ, float* dW, float* db, int M, int N, int K,
+                             float* workspace, hipStream_t stream) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const int splits = dtf_dense_bwd_dw_splits(M, N, K);
+    GemmArgs a = {};
+    a.A = X; a.lda = K;       // A(i=kin, k=m) = X[m*K + kin] -> i-contiguous
+    a.B = dZ; a.ldb = N;
+    a.M = K; a.N = N; a.K = M;
+    a.ldc = N;
+    int chunk = (M + splits - 1) / splits;
+    chunk = ((chunk + BK - 1) / BK) * BK;
+    a.k_chunk = chunk;
+    const int eff_splits = (M + chunk - 1) / chunk;
+    if (eff_splits <= 1) {
+        a.C = dW; a.c_split_stride = 0; a.colsum = db;
+        return launch_gemm<false, false, EPI_DW>(a, 1, stream);
+    }
+    const long long kn = (long long)K * N;
+    a.C = workspace; a.c_split_stride = kn;
+    a.colsum = db ? workspace + (long long)eff_splits * kn : nullptr;
+    int rc = launch_gemm<false, false, EPI_DW>(a, eff_splits, stream);
+    if (rc) return rc;
+    int blocks = (int)((kn / 4 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, stream, workspace, kn, eff_splits, dW, kn);
+    DTF_CHECK_LAUNCH();
+    if (db) {
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3((N + 255) / 256), dim3(256), 0, stream,
+                           workspace + (long long)eff_splits * kn, (long long)N, eff_splits, db, (long long)N);
+        DTF_CHECK_LAUNCH();
+    }
+    return 0;
+}

@@ -1,0 +1,139 @@
+// Apply-gradients kernels over a FLAT parameter range.
+//
+// Variables, gradients and optimizer slots of a model live in contiguous flat fp32
+// buffers, so "apply all variables" and "apply my 1/N shard" are the same kernel on a
+// different [begin, end) range: no pointer tables, 16-byte vector access, grid-stride.
+//
+// Adam follows the TensorFlow ApplyAdam formula used by tf.train.AdamOptimizer at
+// /root/reference/example.py:168-170 (epsilon OUTSIDE the bias correction):
+//     lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t),  t = global_step + 1
+//     m   <- b1 m + (1 - b1) g
+//     v   <- b2 v + (1 - b2) g^2
+//     var <- var - lr_t m / (sqrt(v) + eps)
+// global_step is device-resident (int64) so a captured hipGraph advances by itself.
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ var, float* __restrict__ m,
+                                                   float* __restrict__ v, const float* __restrict__ g,
+                                                   long long n, float lr, float b1, float b2, float eps,
+                                                   float grad_scale, const long long* __restrict__ step_ptr) {
+    const float t = (float)(*step_ptr + 1);
+    const float b1t = powf(b1, t), b2t = powf(b2, t);
+    const float lr_t = lr * sqrtf(1.0f - b2t) / (1.0f - b1t);
+    const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
+    const long long n4 = n >> 2;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    f32x4* var4 = reinterpret_cast<f32x4*>(var);
+    f32x4* m4 = reinterpret_cast<f32x4*>(m);
+    f32x4* v4 = reinterpret_cast<f32x4*>(v);
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(g);
+    for (long long i = tid; i < n4; i += stride) {
+        f32x4 gg = g4[i], mm = m4[i], vv = v4[i], w = var4[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float gj = gg[j] * grad_scale;
+            mm[j] = b1 * mm[j] + omb1 * gj;
+            vv[j] = b2 * vv[j] + omb2 * gj * gj;
+            w[j] -= lr_t * mm[j] / (sqrtf(vv[j]) + eps);
+        }
+        m4[i] = mm;
+        v4[i] = vv;
+        var4[i] = w;
+    }
+    for (long long i = (n4 << 2) + tid; i < n; i += stride) {
+        const float gj = g[i] * grad_scale;
+        const float mj = b1 * m[i] + omb1 * gj;
+        const float vj = b2 * v[i] + omb2 * gj * gj;
+        m[i] = mj;
+        v[i] = vj;
+        var[i] -= lr_t * mj / (sqrtf(vj) + eps);
+    }
+}
+
+// var <- var - lr * (momentum-filtered) g.  mom == nullptr: plain SGD (tf.train.GradientDescentOptimizer).
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ var, float* __restrict__ mom,
+                                                  const float* __restrict__ g, long long n, float lr,
+                                                  float momentum, float grad_scale) {
+    const long long n4 = n >> 2;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    f32x4* var4 = reinterpret_cast<f32x4*>(var);
+    f32x4* mo4 = reinterpret_cast<f32x4*>(mom);
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(g);
+    for (long long i = tid; i < n4; i += stride) {
+        f32x4 gg = g4[i], w = var4[i];
+        if (mom) {
+            f32x4 a = mo4[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a[j] = momentum * a[j] + gg[j] * grad_scale;
+                w[j] -= lr * a[j];
+            }
+            mo4[i] = a;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[j] -= lr * gg[j] * grad_scale;
+        }
+        var4[i] = w;
+    }
+    for (long long i = (n4 << 2) + tid; i < n; i += stride) {
+        float gj = g[i] * grad_scale;
+        if (mom) {
+            gj = momentum * mom[i] + gj;
+            mom[i] = gj;
+        }
+        var[i] -= lr * gj;
+    }
+}
+
+// global_step += 1 and the TF non-slot variables beta1_power / beta2_power *= beta.
+__global__ void step_advance_kernel(long long* step_ptr, float* beta_powers, float b1, float b2) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        *step_ptr += 1;
+        if (beta_powers) {
+            beta_powers[0] *= b1;
+            beta_powers[1] *= b2;
+        }
+    }
+}
+
+inline int flat_grid(long long n) {
+    long long g = (n / 4 + 255) / 256;
+    if (g > 2048) g = 2048;
+    return g < 1 ? 1 : (int)g;
+}
+
+}  // namespace
+
+DTF_API int dtf_adam_apply(float* var, float* m, float* v, const float* g, long long n, float lr, float b1,
+                           float b2, float eps, float grad_scale, const long long* step_ptr,
+                           hipStream_t stream) {
+    if (n <= 0) return 0;
+    if ((reinterpret_cast<uintptr_t>(var) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v) |
+         reinterpret_cast<uintptr_t>(g)) & 15)
+        return -2;  // flat buffers and shard boundaries are 16-byte aligned by construction
+    hipLaunchKernelGGL(adam_kernel, dim3(flat_grid(n)), dim3(256), 0, stream, var, m, v, g, n, lr, b1, b2, eps,
+                       grad_scale, step_ptr);
+    DTF_CHECK_LAUNCH();
+    return 0;
+}
+
+DTF_API int dtf_sgd_apply(float* var, float* mom, const float* g, long long n, float lr, float momentum,
+                          float grad_scale, hipStream_t stream) {
+    if (n <= 0) return 0;
+    if ((reinterpret_cast<uintptr_t>(var) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(mom)) & 15)
+        return -2;
+    hipLaunchKernelGGL(sgd_kernel, dim3(flat_grid(n)), dim3(256), 0, stream, var, mom, g, n, lr, momentum,
+                       grad_scale);
+    DTF_CHECK_LAUNCH();
+    return 0;
+}
+
+DTF_API int dtf_step_advance(long long* step_ptr, float* beta_powers, float b1, float b2, hipStream_t stream) {
+    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, stream, step_ptr, beta_powers, b1, b2);
+    DTF_CHECK_LAUNCH();
+    return 0;
+}

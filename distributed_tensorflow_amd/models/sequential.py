@@ -1,0 +1,392 @@
+"""``Sequential`` / ``compile`` / ``fit`` / ``evaluate`` / ``predict``.
+
+The Keras workflow of /root/reference/example2.py:151-165,200, made to actually work on
+the cluster runtime (the reference's own ``fit`` call sits inside a finalized TF graph).
+
+Execution model: a training step is a fixed list of kernel launches (forward GEMMs with
+fused bias/activation/dropout, one fused loss+gradient kernel, backward GEMMs, one fused
+apply-gradients launch over the flat variable buffer).  Nothing in a step synchronises
+with the host: loss/accuracy accumulate in a device-resident statistics record that is
+read once per epoch (or whenever a callback asks), and ``steps_per_graph`` lets ``fit``
+replay many steps from one captured hipGraph when batches are launch-bound.
+"""
+from __future__ import annotations
+
+import math
+import time
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from .. import callbacks as cb
+from .. import losses as losses_mod
+from .. import optimizers as optim_mod
+from ..layers import Dense, Dropout, Layer
+from ..ops import functional as F
+from ..ops._native import ACT_NONE, ACT_RELU, ACT_SIGMOID
+from ..variables import VariableStore
+
+
+def default_device() -> torch.device:
+    return torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+
+
+def _as_tensor(a, device, dtype=None) -> torch.Tensor:
+    if isinstance(a, torch.Tensor):
+        t = a
+    else:
+        t = torch.as_tensor(a)
+    if dtype is None:
+        dtype = torch.int64 if t.dtype in (torch.int64, torch.int32, torch.int16, torch.uint8) and t.dim() == 1 \
+            else torch.float32
+    return t.to(device=device, dtype=dtype).contiguous()
+
+
+class LocalStrategy:
+    """Single-replica update: apply the whole flat gradient, advance global_step."""
+
+    world_size = 1
+    rank = 0
+
+    def prepare(self, model):
+        pass
+
+    def apply_gradients(self, model):
+        model.optimizer.apply(model.store)
+        model.optimizer.finish_step(model.store)
+
+    def reduce_stats(self, stats: torch.Tensor) -> torch.Tensor:
+        return stats
+
+
+class Sequential:
+    def __init__(self, layers: Optional[Sequence[Layer]] = None, name: str = "sequential"):
+        self.name = name
+        self.layers: List[Layer] = []
+        self.store = VariableStore()
+        self.built = False
+        self.compiled = False
+        self.loss = None
+        self.optimizer = None
+        self.metrics: List[str] = []
+        self.strategy = LocalStrategy()
+        self.device: Optional[torch.device] = None
+        self.stats: Optional[torch.Tensor] = None
+        self.stop_training = False
+        self._grad_buf: Dict = {}
+        self._host_step = 0           # host mirror of global_step (no device sync needed)
+        self._graphs: Dict = {}
+        self._after_layer_backward = None   # strategy hook: called as each layer's gradients become final
+        for layer in layers or []:
+            self.add(layer)
+
+    # ------------------------------------------------------------------ construction
+    def add(self, layer: Layer):
+        if self.built:
+            raise RuntimeError("cannot add layers after the model is built")
+        if not self.layers and layer.input_shape is None:
+            # shape may still arrive through build(input_shape=...)
+            pass
+        self.layers.append(layer)
+
+    def build(self, input_shape=None, device=None, seed: Optional[int] = None, pad_multiple: int = 64):
+        if self.built:
+            return self
+        if input_shape is None:
+            input_shape = self.layers[0].input_shape
+        if input_shape is None:
+            raise ValueError("first layer needs input_dim= / input_shape= (or pass build(input_shape=...))")
+        shape = tuple(input_shape)
+        self.input_shape = shape
+        for layer in self.layers:
+            shape = layer.build(shape, self.store)
+        self.output_shape = shape
+        self._plan_fusion()
+        self.device = torch.device(device) if device is not None else default_device()
+        self.store.finalize(self.device, seed=seed, pad_multiple=pad_multiple)
+        self.stats = F.new_stats(self.device)
+        self.built = True
+        return self
+
+    def _plan_fusion(self):
+        """Fold Dropout into the preceding ReLU Dense and activation gradients into the next dgrad GEMM."""
+        L = self.layers
+        for i, layer in enumerate(L):
+            if isinstance(layer, Dropout) and i > 0 and isinstance(L[i - 1], Dense) \
+                    and L[i - 1].act == ACT_RELU and not L[i - 1].softmax and layer.rate > 0.0:
+                L[i - 1].fused_keep = 1.0 - layer.rate
+                L[i - 1].seed = layer.seed
+                layer.fused_into_previous = True
+        # chain of "effective" layers (skipping folded dropouts)
+        eff = [l for l in L if not (isinstance(l, Dropout) and l.fused_into_previous)]
+        for a, b in zip(eff[:-1], eff[1:]):
+            if isinstance(a, Dense) and isinstance(b, Dense) and not a.softmax and a.act in (ACT_RELU, ACT_SIGMOID) \
+                    and not (a.act == ACT_SIGMOID and a.fused_keep < 1.0):
+                b.fuse_prev_grad = True
+                b.prev_act = a.act
+                b.prev_scale = 1.0 / a.fused_keep
+                a.grad_is_dz = True
+        if eff:
+            eff[0].need_input_grad = False
+        self._effective = eff
+
+    # ------------------------------------------------------------------ compile
+    def compile(self, loss="mean_squared_error", optimizer="adam", metrics: Optional[Sequence[str]] = None,
+                strategy=None, device=None, seed: Optional[int] = None):
+        self.loss = losses_mod.get(loss)
+        self.optimizer = optim_mod.get(optimizer)
+        self.metrics = list(metrics or [])
+        if strategy is not None:
+            self.strategy = strategy
+        if not self.built:
+            pad = self.strategy.var_alignment() if hasattr(self.strategy, "var_alignment") else 64
+            self.build(device=device, seed=seed, pad_multiple=pad)
+        head = self._effective[-1] if self._effective else None
+        if isinstance(head, Dense):
+            if self.loss.wants_logits:
+                if head.act != ACT_NONE:
+                    raise ValueError("%s expects a linear or softmax head, got activation=%r"
+                                     % (self.loss.name, head.activation))
+                head.emit_logits = True
+            if self.loss.fuse_with_head(head):
+                head.grad_is_dz = True
+        self.optimizer.create_slots(self.store)
+        self.strategy.prepare(self)
+        # Keras rule: 'accuracy' with a non-crossentropy loss and output dim > 1 is categorical accuracy.
+        self._extra_categorical = any(m in ("accuracy", "acc", "categorical_accuracy") for m in self.metrics) \
+            and self.loss.primary_metric != "categorical"
+        self._report_binary = any(m in ("binary_rounded_accuracy", "xor_accuracy", "bit_accuracy")
+                                  for m in self.metrics)
+        self.compiled = True
+        return self
+
+    # ------------------------------------------------------------------ execution pieces
+    def forward(self, x: torch.Tensor, training: bool = False) -> torch.Tensor:
+        h = x
+        for layer in self.layers:
+            h = layer.forward(h, training)
+        return h
+
+    def backward(self, dy: torch.Tensor):
+        g = dy
+        hook = self._after_layer_backward
+        for layer in reversed(self.layers):
+            g = layer.backward(g)
+            if hook is not None:
+                hook(layer, self)
+            if g is None:
+                break
+
+    def _grad_like(self, out: torch.Tensor) -> torch.Tensor:
+        key = (tuple(out.shape), str(out.device))
+        t = self._grad_buf.get(key)
+        if t is None:
+            t = torch.empty_like(out)
+            self._grad_buf[key] = t
+        return t
+
+    def _loss_and_metrics(self, out, y, want_grad: bool, stats: torch.Tensor):
+        g = self._grad_like(out) if want_grad else None
+        self.loss(out, y, g, stats)
+        if self._extra_categorical:
+            F.categorical_accuracy_sum(out, y if y.dim() == 2 else
+                                       torch.nn.functional.one_hot(y, out.shape[1]).to(torch.float32),
+                                       stats[3:4])
+        return g
+
+    def compute_gradients(self, x, y, stats: Optional[torch.Tensor] = None):
+        """Forward + loss + backward: leaves dL/dvar in ``store.flat_grad`` (no variable update)."""
+        out = self.forward(x, training=True)
+        g = self._loss_and_metrics(out, y, True, self.stats if stats is None else stats)
+        self.backward(g)
+
+    def train_step(self, x: torch.Tensor, y: torch.Tensor):
+        """One optimisation step on a device-resident batch; returns nothing (no host sync)."""
+        self.compute_gradients(x, y)
+        self.strategy.apply_gradients(self)
+        self._host_step += 1
+
+    # ------------------------------------------------------------------ statistics
+    def read_stats(self, reset: bool = True, stats: Optional[torch.Tensor] = None) -> Dict[str, float]:
+        """Mean loss / accuracy since the last reset (ONE device->host read)."""
+        s = self.stats if stats is None else stats
+        red = self.strategy.reduce_stats(s) if stats is None else s
+        vals = red.tolist()
+        n = max(vals[2], 1.0)
+        logs = {"loss": vals[0] / n}
+        if self.metrics:
+            if self._extra_categorical:
+                logs["acc"] = vals[3] / n
+                if self._report_binary:
+                    logs["binary_rounded_accuracy"] = vals[1] / n
+            else:
+                logs["acc"] = vals[1] / n
+        if reset:
+            s.zero_()
+        return logs
+
+    @property
+    def global_step(self) -> int:
+        return int(self.store.global_step.item())
+
+    # ------------------------------------------------------------------ Keras entry points
+    def train_on_batch(self, x, y) -> Dict[str, float]:
+        self._check_compiled()
+        xb, yb = _as_tensor(x, self.device), _as_tensor(y, self.device)
+        self.stats.zero_()
+        self.train_step(xb, yb)
+        return self.read_stats()
+
+    def test_on_batch(self, x, y) -> Dict[str, float]:
+        self._check_compiled()
+        xb, yb = _as_tensor(x, self.device), _as_tensor(y, self.device)
+        st = F.new_stats(self.device)
+        out = self.forward(xb, training=False)
+        self._loss_and_metrics(out, yb, False, st)
+        return self.read_stats(stats=st)
+
+    def evaluate(self, x, y, batch_size: int = 32, verbose: int = 0) -> List[float]:
+        self._check_compiled()
+        xd, yd = _as_tensor(x, self.device), _as_tensor(y, self.device)
+        st = F.new_stats(self.device)
+        n = xd.shape[0]
+        for i in range(0, n, batch_size):
+            out = self.forward(xd[i:i + batch_size], training=False)
+            self._loss_and_metrics(out, yd[i:i + batch_size], False, st)
+        logs = self.read_stats(stats=self.strategy.reduce_stats(st))
+        return [logs["loss"]] + ([logs["acc"]] if "acc" in logs else [])
+
+    def predict(self, x, batch_size: int = 32) -> torch.Tensor:
+        if not self.built:
+            raise RuntimeError("model is not built")
+        xd = _as_tensor(x, self.device)
+        outs = []
+        head = self._effective[-1] if self._effective else None
+        for i in range(0, xd.shape[0], batch_size):
+            out = self.forward(xd[i:i + batch_size], training=False)
+            if isinstance(head, Dense) and head.softmax and head.emit_logits:
+                out = F.softmax(out)
+            outs.append(out.clone())
+        return torch.cat(outs, dim=0)
+
+    def _check_compiled(self):
+        if not self.compiled:
+            raise RuntimeError("call compile() first")
+
+    # ------------------------------------------------------------------ graph-captured steps
+    def _graphed_steps(self, x_buf: torch.Tensor, y_buf: torch.Tensor, batch_size: int, nsteps: int):
+        """Capture ``nsteps`` consecutive training steps reading ``x_buf[k*B:(k+1)*B]`` into one hipGraph."""
+        key = (x_buf.data_ptr(), y_buf.data_ptr(), batch_size, nsteps)
+        g = self._graphs.get(key)
+        if g is not None:
+            return g
+        # warm-up outside capture so every lazily allocated buffer exists
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        saved = self._snapshot()
+        with torch.cuda.stream(side):
+            self.train_step(x_buf[:batch_size], y_buf[:batch_size])
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._restore(saved)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for k in range(nsteps):
+                self.train_step(x_buf[k * batch_size:(k + 1) * batch_size],
+                                y_buf[k * batch_size:(k + 1) * batch_size])
+        self._host_step -= nsteps + 1  # capture and warm-up did not execute training steps
+        self._graphs[key] = g
+        return g
+
+    def _snapshot(self):
+        st = self.store
+        return (st.flat.clone(), {k: v.clone() for k, v in st.slots.items()}, st.global_step.clone(),
+                st.beta_powers.clone(), self.stats.clone())
+
+    def _restore(self, saved):
+        st = self.store
+        st.flat.copy_(saved[0])
+        for k, v in saved[1].items():
+            st.slots[k].copy_(v)
+        st.global_step.copy_(saved[2])
+        st.beta_powers.copy_(saved[3])
+        self.stats.copy_(saved[4])
+
+    # ------------------------------------------------------------------ fit
+    def fit(self, x, y, epochs: int = 1, batch_size: int = 32, validation_data=None, callbacks=None,
+            shuffle: bool = True, verbose: int = 1, steps_per_graph: int = 0, initial_epoch: int = 0):
+        """Keras ``fit``.  Data is moved to the device once; each epoch reshuffles on the device.
+
+        ``steps_per_graph > 0`` (GPU only) replays that many consecutive steps from one
+        captured hipGraph; 0 launches every kernel eagerly.
+        """
+        self._check_compiled()
+        xd, yd = _as_tensor(x, self.device), _as_tensor(y, self.device)
+        n = xd.shape[0]
+        val = None
+        if validation_data is not None:
+            val = (_as_tensor(validation_data[0], self.device), _as_tensor(validation_data[1], self.device))
+        steps = int(math.ceil(n / float(batch_size)))
+        params = {"epochs": epochs, "batch_size": batch_size, "steps": steps, "samples": n,
+                  "metrics": ["loss"] + (["acc"] if self.metrics else [])}
+        history = cb.History()
+        cbs = [history] + ([cb.ProgbarLogger()] if verbose else []) + list(callbacks or [])
+        cl = cb.CallbackList(cbs, self, params)
+        self.stop_training = False
+        cl.call("on_train_begin", None)
+        use_graph = steps_per_graph > 0 and self.device.type == "cuda"
+        x_ep = torch.empty_like(xd) if (shuffle or use_graph) else xd
+        y_ep = torch.empty_like(yd) if (shuffle or use_graph) else yd
+        full_steps = n // batch_size
+        for epoch in range(initial_epoch, epochs):
+            if self.stop_training:
+                break
+            cl.call("on_epoch_begin", epoch, None)
+            if shuffle:
+                perm = torch.randperm(n, device=self.device)
+                torch.index_select(xd, 0, perm, out=x_ep)
+                torch.index_select(yd, 0, perm, out=y_ep)
+            elif use_graph and x_ep is not xd:
+                x_ep.copy_(xd)
+                y_ep.copy_(yd)
+            self.stats.zero_()
+            done = 0
+            if use_graph:
+                while full_steps - done >= steps_per_graph:
+                    off = done * batch_size
+                    span = steps_per_graph * batch_size
+                    g = self._graphed_steps(x_ep[off:off + span], y_ep[off:off + span], batch_size, steps_per_graph)
+                    g.replay()
+                    self._host_step += steps_per_graph
+                    done += steps_per_graph
+                    if cl.wants_batch_logs:
+                        cl.call("on_batch_end", done - 1, {})
+            for s in range(done, steps):
+                xb = x_ep[s * batch_size:(s + 1) * batch_size]
+                yb = y_ep[s * batch_size:(s + 1) * batch_size]
+                self.train_step(xb, yb)
+                if cl.wants_batch_logs:
+                    cl.call("on_batch_end", s, {})
+            logs = self.read_stats()
+            if val is not None:
+                ev = self.evaluate(val[0], val[1], batch_size=max(batch_size, 1))
+                logs["val_loss"] = ev[0]
+                if len(ev) > 1:
+                    logs["val_acc"] = ev[1]
+            cl.call("on_epoch_end", epoch, logs)
+        cl.call("on_train_end", None)
+        return history
+
+    # ------------------------------------------------------------------ misc
+    def summary(self) -> str:
+        lines = ["Model: %s" % self.name, "%-28s %-20s %10s" % ("Layer (type)", "Output Shape", "Param #")]
+        total = 0
+        for l in self.layers:
+            n = sum(v.numel for v in l.variables)
+            total += n
+            lines.append("%-28s %-20s %10d" % ("%s (%s)" % (l.name, type(l).__name__), str((None,) + tuple(l.output_shape or ())), n))
+        lines.append("Total params: %d" % total)
+        return "\n".join(lines)
+
+    def get_config(self):
+        return {"name": self.name, "layers": [l.get_config() for l in self.layers]}

@@ -1,0 +1,376 @@
+"""Functional front-end of the hot ops.
+
+Each function dispatches on the device of its tensors:
+
+* GPU tensors -> the hand-written HIP kernels in ``csrc/kernels`` (launched on the
+  current PyTorch stream, so they are captured by ``torch.cuda.graph``);
+* CPU tensors -> a plain-PyTorch fp32 reference of the same math.  The reference is
+  what the multi-process gloo tests run and what the GPU numerics tests compare to.
+
+The ops mirror what one ``sess.run([accuracy, loss, summ, train_step])`` executes in
+/root/reference/example.py:213 (dense forward, dropout, MSE, accuracy, their gradients
+and the Adam apply).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _native as nv
+from ._native import ACT_CODES, ACT_NONE, ACT_RELU, ACT_SIGMOID  # noqa: F401
+
+_M32 = 0xFFFFFFFF
+
+
+# --------------------------------------------------------------------------- RNG (CPU mirror of common.h)
+def _mix32(x: torch.Tensor) -> torch.Tensor:
+    x = x & _M32
+    x = x ^ (x >> 16)
+    x = (x * 0x7FEB352D) & _M32
+    x = x ^ (x >> 15)
+    x = (x * 0x846CA68B) & _M32
+    x = x ^ (x >> 16)
+    return x
+
+
+def _mix32_int(x: int) -> int:
+    x &= _M32
+    x ^= x >> 16
+    x = (x * 0x7FEB352D) & _M32
+    x ^= x >> 15
+    x = (x * 0x846CA68B) & _M32
+    x ^= x >> 16
+    return x
+
+
+def dropout_key(seed: int, step: int) -> int:
+    k = _mix32_int((step & _M32) + 0x9E3779B9)
+    k = _mix32_int(k ^ (((step >> 32) & _M32) * 0x85EBCA6B & _M32) ^ (seed & _M32))
+    return k
+
+
+def dropout_uniform(key: int, n: int, device="cpu") -> torch.Tensor:
+    """u[i] in [0,1) for flat element index i: bit-identical to ``dtf_uniform`` on the GPU."""
+    idx = torch.arange(n, dtype=torch.int64, device=device)
+    r = _mix32(((idx & _M32) * 0x9E3779B1 + key) & _M32)
+    r = _mix32(r ^ (((idx >> 32) + 0x632BE5AB) & _M32) ^ (key >> 7))
+    return (r >> 8).to(torch.float32) * (1.0 / 16777216.0)
+
+
+def _step_value(step) -> int:
+    if step is None:
+        return 0
+    if isinstance(step, torch.Tensor):
+        return int(step.item())
+    return int(step)
+
+
+# --------------------------------------------------------------------------- dense layer
+def _apply_act(z: torch.Tensor, act: int) -> torch.Tensor:
+    if act == ACT_RELU:
+        return torch.relu(z)
+    if act == ACT_SIGMOID:
+        return torch.sigmoid(z)
+    return z
+
+
+def dense_forward(x, w, b=None, act=ACT_NONE, keep=1.0, seed=0, step=None, out=None):
+    """``dropout(act(x @ w + b))`` with inverted dropout (keep probability ``keep``)."""
+    M, K = x.shape
+    K2, N = w.shape
+    assert K == K2, "x[%d,%d] @ w[%d,%d]" % (M, K, K2, N)
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    if x.is_cuda:
+        nv.require_f32_contig(x, w, b, out)
+        if step is not None:
+            assert step.dtype == torch.int64 and step.is_cuda
+        rc = nv.kernels().dtf_dense_fwd(nv.ptr(x), nv.ptr(w), nv.ptr(b), nv.ptr(out), M, N, K, int(act),
+                                        float(keep), int(seed) & _M32, nv.ptr(step), nv.stream_ptr())
+        nv.check(rc, "dtf_dense_fwd")
+        return out
+    z = x @ w
+    if b is not None:
+        z = z + b
+    y = _apply_act(z, act)
+    if keep < 1.0:
+        u = dropout_uniform(dropout_key(seed, _step_value(step)), M * N).view(M, N)
+        y = torch.where(u < keep, y * (1.0 / keep), torch.zeros_like(y))
+    out.copy_(y)
+    return out
+
+
+def dense_backward_dx(dz, w, yprev=None, act_prev=ACT_NONE, scale_prev=1.0, out=None):
+    """``dz @ w.T`` followed by the producing layer's activation/dropout gradient.
+
+    ``yprev`` is the producing layer's OUTPUT (this layer's input).  relu(+dropout):
+    ``(yprev > 0) * scale_prev``; sigmoid: ``yprev * (1 - yprev)``.
+    """
+    M, N = dz.shape
+    K, N2 = w.shape
+    assert N == N2
+    if out is None:
+        out = torch.empty((M, K), dtype=torch.float32, device=dz.device)
+    if dz.is_cuda:
+        nv.require_f32_contig(dz, w, yprev, out)
+        rc = nv.kernels().dtf_dense_bwd_dx(nv.ptr(dz), nv.ptr(w), nv.ptr(out), M, N, K, nv.ptr(yprev),
+                                           int(act_prev), float(scale_prev), nv.stream_ptr())
+        nv.check(rc, "dtf_dense_bwd_dx")
+        return out
+    dx = dz @ w.t()
+    if yprev is not None:
+        if act_prev == ACT_RELU:
+            dx = torch.where(yprev > 0, dx * scale_prev, torch.zeros_like(dx))
+        elif act_prev == ACT_SIGMOID:
+            dx = dx * yprev * (1.0 - yprev)
+    out.copy_(dx)
+    return out
+
+
+def dense_dw_workspace_floats(M: int, N: int, K: int) -> int:
+    """Floats of scratch ``dense_backward_dw`` needs for a [M,K] x [M,N] weight gradient."""
+    if not nv.kernels_available():
+        return 0
+    s = nv.kernels().dtf_dense_bwd_dw_splits(M, N, K)
+    return s * (K * N + N) if s > 1 else 0
+
+
+def dense_backward_dw(x, dz, dw, db=None, workspace=None):
+    """``dw = x.T @ dz`` and ``db = dz.sum(0)`` written into the given (flat-buffer) views."""
+    M, K = x.shape
+    M2, N = dz.shape
+    assert M == M2 and tuple(dw.shape) == (K, N)
+    if x.is_cuda:
+        nv.require_f32_contig(x, dz, dw, db)
+        need = dense_dw_workspace_floats(M, N, K)
+        if need and (workspace is None or workspace.numel() < need):
+            workspace = torch.empty(need, dtype=torch.float32, device=x.device)
+        rc = nv.kernels().dtf_dense_bwd_dw(nv.ptr(x), nv.ptr(dz), nv.ptr(dw), nv.ptr(db), M, N, K,
+                                           nv.ptr(workspace), nv.stream_ptr())
+        nv.check(rc, "dtf_dense_bwd_dw")
+        return dw, db
+    dw.copy_(x.t() @ dz)
+    if db is not None:
+        db.copy_(dz.sum(0))
+    return dw, db
+
+
+def act_grad(dy, y, act, scale=1.0, out=None):
+    """``dz = dy * act'(y)`` (relu/sigmoid expressed through the activation OUTPUT)."""
+    if out is None:
+        out = torch.empty_like(dy)
+    if dy.is_cuda:
+        nv.require_f32_contig(dy, y, out)
+        rc = nv.kernels().dtf_act_grad(nv.ptr(dy), nv.ptr(y), nv.ptr(out), dy.numel(), int(act), float(scale),
+                                       nv.stream_ptr())
+        nv.check(rc, "dtf_act_grad")
+        return out
+    if act == ACT_RELU:
+        r = torch.where(y > 0, dy * scale, torch.zeros_like(dy))
+    elif act == ACT_SIGMOID:
+        r = dy * y * (1.0 - y)
+    else:
+        r = dy * scale
+    out.copy_(r)
+    return out
+
+
+def dropout(x, keep, seed=0, step=None, out=None):
+    """Inverted dropout with a mask that is a pure function of (seed, step, index).
+
+    Calling it again on a gradient with the same (seed, step) applies the same mask, which
+    is the backward pass.
+    """
+    if out is None:
+        out = torch.empty_like(x)
+    if x.is_cuda:
+        nv.require_f32_contig(x, out)
+        rc = nv.kernels().dtf_dropout(nv.ptr(x), nv.ptr(out), x.numel(), float(keep), int(seed) & _M32,
+                                      nv.ptr(step), nv.stream_ptr())
+        nv.check(rc, "dtf_dropout")
+        return out
+    u = dropout_uniform(dropout_key(seed, _step_value(step)), x.numel()).view(x.shape)
+    out.copy_(torch.where(u < keep, x * (1.0 / keep), torch.zeros_like(x)))
+    return out
+
+
+def activation_forward(x, act, out=None):
+    """Stand-alone activation (the fused form lives in the dense forward epilogue)."""
+    if out is None:
+        out = torch.empty_like(x)
+    if x.is_cuda:
+        nv.require_f32_contig(x, out)
+        rc = nv.kernels().dtf_activation(nv.ptr(x), nv.ptr(out), x.numel(), int(act), nv.stream_ptr())
+        nv.check(rc, "dtf_activation")
+        return out
+    out.copy_(_apply_act(x, act))
+    return out
+
+
+def softmax(z, out=None):
+    """Row softmax of logits [M, C]."""
+    if out is None:
+        out = torch.empty_like(z)
+    M, Cn = z.shape
+    if z.is_cuda:
+        nv.require_f32_contig(z, out)
+        rc = nv.kernels().dtf_softmax_rows(nv.ptr(z), nv.ptr(out), M, Cn, nv.stream_ptr())
+        nv.check(rc, "dtf_softmax_rows")
+        return out
+    out.copy_(torch.softmax(z, dim=1))
+    return out
+
+
+# --------------------------------------------------------------------------- losses / metrics
+def new_stats(device) -> torch.Tensor:
+    """Running-statistics record: [sum of per-example loss, sum of per-example accuracy, examples, unused]."""
+    return torch.zeros(4, dtype=torch.float32, device=device)
+
+
+def mse_loss(p, y, grad_out=None, grad_scale=None, through_sigmoid=False, stats=None):
+    """Keras ``mean_squared_error`` + rounded-equality accuracy, gradient fused.
+
+    ``grad_out`` (optional, same shape as ``p``) receives d(mean loss)/dp, multiplied by
+    ``p (1 - p)`` when ``through_sigmoid`` (the gradient w.r.t. the pre-sigmoid logits).
+    ``stats`` accumulates (loss sum, accuracy sum, example count).
+    """
+    M, N = p.shape
+    if grad_scale is None:
+        grad_scale = 1.0 / (M * N)
+    if p.is_cuda:
+        nv.require_f32_contig(p, y, grad_out, stats)
+        rc = nv.kernels().dtf_mse_loss(nv.ptr(p), nv.ptr(y), nv.ptr(grad_out), M, N, float(grad_scale),
+                                       int(bool(through_sigmoid)), nv.ptr(stats), nv.stream_ptr())
+        nv.check(rc, "dtf_mse_loss")
+        return grad_out
+    d = p - y
+    if grad_out is not None:
+        g = 2.0 * d * grad_scale
+        if through_sigmoid:
+            g = g * p * (1.0 - p)
+        grad_out.copy_(g)
+    if stats is not None:
+        stats[0] += (d * d).mean(dim=1).sum()
+        stats[1] += (torch.round(p) == torch.round(y)).to(torch.float32).mean(dim=1).sum()
+        stats[2] += float(M)
+    return grad_out
+
+
+def softmax_xent(z, labels, grad_out=None, grad_scale=None, stats=None):
+    """Softmax cross-entropy on logits ``z`` [M,C] + argmax accuracy, gradient fused.
+
+    ``labels`` is int64 [M] (sparse) or float32 [M,C] (one-hot / distribution).
+    """
+    M, Cn = z.shape
+    if grad_scale is None:
+        grad_scale = 1.0 / M
+    sparse = labels.dtype == torch.int64
+    if z.is_cuda:
+        nv.require_f32_contig(z, grad_out, stats)
+        assert labels.is_contiguous()
+        if not sparse:
+            nv.require_f32_contig(labels)
+        rc = nv.kernels().dtf_softmax_xent(nv.ptr(z), nv.ptr(labels) if sparse else 0,
+                                           0 if sparse else nv.ptr(labels), nv.ptr(grad_out), M, Cn,
+                                           float(grad_scale), nv.ptr(stats), nv.stream_ptr())
+        nv.check(rc, "dtf_softmax_xent")
+        return grad_out
+    logp = torch.log_softmax(z, dim=1)
+    sm = logp.exp()
+    if sparse:
+        onehot = torch.zeros_like(z).scatter_(1, labels.view(-1, 1), 1.0)
+        label_arg = labels
+    else:
+        onehot = labels
+        label_arg = labels.argmax(dim=1)
+    if grad_out is not None:
+        grad_out.copy_((sm * onehot.sum(dim=1, keepdim=True) - onehot) * grad_scale)
+    if stats is not None:
+        stats[0] += -(onehot * logp).sum()
+        stats[1] += (z.argmax(dim=1) == label_arg).to(torch.float32).sum()
+        stats[2] += float(M)
+    return grad_out
+
+
+def categorical_accuracy_sum(p, y, acc_sum):
+    """acc_sum[0] += number of rows with argmax(p) == argmax(y) (Keras categorical_accuracy)."""
+    M, N = p.shape
+    if p.is_cuda:
+        nv.require_f32_contig(p, y, acc_sum)
+        rc = nv.kernels().dtf_categorical_accuracy(nv.ptr(p), nv.ptr(y), M, N, nv.ptr(acc_sum), nv.stream_ptr())
+        nv.check(rc, "dtf_categorical_accuracy")
+        return acc_sum
+    acc_sum[0] += (p.argmax(dim=1) == y.argmax(dim=1)).to(torch.float32).sum()
+    return acc_sum
+
+
+# --------------------------------------------------------------------------- optimizers
+def adam_apply(var, m, v, grad, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    """TensorFlow-formula Adam on flat fp32 ranges; ``step`` is the int64 global_step BEFORE this update."""
+    n = var.numel()
+    assert m.numel() == n and v.numel() == n and grad.numel() == n
+    if var.is_cuda:
+        nv.require_f32_contig(var, m, v, grad)
+        rc = nv.kernels().dtf_adam_apply(nv.ptr(var), nv.ptr(m), nv.ptr(v), nv.ptr(grad), n, float(lr),
+                                         float(beta1), float(beta2), float(eps), float(grad_scale),
+                                         nv.ptr(step), nv.stream_ptr())
+        nv.check(rc, "dtf_adam_apply")
+        return var
+    t = float(_step_value(step) + 1)
+    b1 = torch.tensor(beta1, dtype=torch.float32)
+    b2 = torch.tensor(beta2, dtype=torch.float32)
+    lr_t = lr * torch.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t)
+    g = grad * grad_scale
+    m.mul_(beta1).add_(g, alpha=1.0 - beta1)
+    v.mul_(beta2).addcmul_(g, g, value=1.0 - beta2)
+    var.sub_(lr_t * m / (v.sqrt() + eps))
+    return var
+
+
+def sgd_apply(var, grad, lr, momentum_buf=None, momentum=0.0, grad_scale=1.0):
+    """``var -= lr * g`` (optionally with a classical momentum accumulator) on flat fp32 ranges."""
+    n = var.numel()
+    if var.is_cuda:
+        nv.require_f32_contig(var, grad, momentum_buf)
+        rc = nv.kernels().dtf_sgd_apply(nv.ptr(var), nv.ptr(momentum_buf), nv.ptr(grad), n, float(lr),
+                                        float(momentum), float(grad_scale), nv.stream_ptr())
+        nv.check(rc, "dtf_sgd_apply")
+        return var
+    g = grad * grad_scale
+    if momentum_buf is not None:
+        momentum_buf.mul_(momentum).add_(g)
+        g = momentum_buf
+    var.sub_(lr * g)
+    return var
+
+
+def step_advance(step, beta_powers=None, beta1=0.9, beta2=0.999):
+    """``global_step += 1``; TF's non-slot ``beta1_power``/``beta2_power`` variables ``*= beta``."""
+    if step.is_cuda:
+        rc = nv.kernels().dtf_step_advance(nv.ptr(step), nv.ptr(beta_powers), float(beta1), float(beta2),
+                                           nv.stream_ptr())
+        nv.check(rc, "dtf_step_advance")
+        return step
+    step += 1
+    if beta_powers is not None:
+        beta_powers[0] *= beta1
+        beta_powers[1] *= beta2
+    return step
+
+
+def xor_data(n, bits, seed, device):
+    """Device-side generator of the XOR task of /root/reference/example.py:24-48."""
+    x = torch.empty((n, 2 * bits), dtype=torch.float32, device=device)
+    y = torch.empty((n, bits), dtype=torch.float32, device=device)
+    if x.is_cuda:
+        rc = nv.kernels().dtf_xor_data(nv.ptr(x), nv.ptr(y), n, bits, int(seed) & _M32, nv.stream_ptr())
+        nv.check(rc, "dtf_xor_data")
+        return x, y
+    s = torch.arange(n, dtype=torch.int64).view(n, 1)
+    k = torch.arange(bits, dtype=torch.int64).view(1, bits)
+    r = _mix32((_mix32(((s * 0x9E3779B1) + (seed & _M32)) & _M32) + ((k * 0x85EBCA6B) & _M32)) & _M32)
+    a = (r >> 9) & 1
+    b = (r >> 21) & 1
+    x[:, :bits] = a.to(torch.float32)
+    x[:, bits:] = b.to(torch.float32)
+    y.copy_((a ^ b).to(torch.float32))
+    return x, y

@@ -1,0 +1,189 @@
+"""Synchronous-replica data parallelism over the sharded flat variable buffer.
+
+TensorFlow's way to make the reference's training synchronous would be
+``SyncReplicasOptimizer`` around the optimizer of /root/reference/example.py:168-170: N
+worker gradients are averaged on the parameter servers, the update is applied once, and
+``global_step`` advances once per aggregated update.  The MI355X design keeps those
+semantics but replaces the PS round trip by collectives on contiguous ranges:
+
+    reduce-scatter(grad bucket)  ->  fused Adam on the 1/N shard this rank owns
+                                 ->  all-gather(updated parameter bucket)
+
+Each rank is therefore the "parameter server" (owner) of 1/N of every bucket: the
+optimizer state it touches and the apply work are sharded N ways, and every xGMI link
+carries 1/N of the data in each collective.  Buckets are built in backward order and
+their reduce-scatter is issued (asynchronously, on RCCL's stream) as soon as the last
+gradient of the bucket has been produced, so communication overlaps the remaining
+backward GEMMs.  Collectives are large by default (64 MiB buckets): ring collectives over
+point-to-point xGMI are per-link bound and launch latency is tens of microseconds, so
+fewer, larger messages win; a model smaller than one bucket is a single collective pair.
+
+In a fully synchronous collective there is no stale gradient to drop (TF's
+``local_step < global_step`` test): every rank contributes exactly one gradient per step.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, List, Optional
+
+import torch
+
+from .comm import Communicator
+
+
+class _Bucket:
+    __slots__ = ("begin", "end", "layers", "pending", "work", "shard", "shard_begin", "shard_end")
+
+    def __init__(self, begin: int, end: int):
+        self.begin, self.end = begin, end
+        self.layers: List = []
+        self.pending = 0
+        self.work = None
+        self.shard: Optional[torch.Tensor] = None
+        self.shard_begin = self.shard_end = 0
+
+
+class SyncReplicasStrategy:
+    def __init__(self, comm: Optional[Communicator] = None, bucket_bytes: int = 64 << 20, overlap: bool = True,
+                 average: bool = True):
+        self.comm = comm if comm is not None else Communicator()
+        self.world_size = self.comm.world_size
+        self.rank = self.comm.rank
+        self.bucket_bytes = int(bucket_bytes)
+        self.overlap = overlap
+        self.average = average
+        self.buckets: List[_Bucket] = []
+        self._layer_bucket: Dict[int, _Bucket] = {}
+        # exercise the real collectives even with one rank (GPU-box test of the RCCL path)
+        self.force = os.environ.get("DTF_FORCE_COLLECTIVES", "0") == "1"
+
+    # ------------------------------------------------------------------ setup
+    def var_alignment(self) -> int:
+        """Variable offsets must be multiples of this so every bucket splits evenly into 16-byte-aligned shards."""
+        return 64 * self.world_size
+
+    def prepare(self, model):
+        store = model.store
+        W = self.world_size
+        if store.flat_len % (64 * W) != 0:
+            raise ValueError("flat buffer (%d) must be padded to 64*world_size; compile() with this strategy "
+                             "before build()" % store.flat_len)
+        for v in store.trainable:
+            if v.offset % (64 * W) != 0:
+                raise ValueError("variable %s offset %d not aligned to %d" % (v.name, v.offset, 64 * W))
+        # the chief's initial values win; everyone else receives them
+        self.comm.broadcast(store.flat, 0)
+        self.comm.broadcast(store.global_step, 0)
+        for s in store.slots.values():
+            self.comm.broadcast(s, 0)
+        self._build_buckets(model)
+        model._after_layer_backward = self._on_layer_backward if self.overlap else None
+
+    def _build_buckets(self, model):
+        store = model.store
+        W = self.world_size
+        layers_with_vars = [l for l in model.layers if l.variables]
+        self.buckets = []
+        self._layer_bucket = {}
+        cur: Optional[_Bucket] = None
+        limit = max(self.bucket_bytes // 4, 64 * W)
+        # walk layers in backward order; a bucket is a contiguous flat range [begin, end)
+        for layer in reversed(layers_with_vars):
+            lo = min(v.offset for v in layer.variables)
+            if cur is None:
+                cur = _Bucket(lo, store.flat_len if not self.buckets else self.buckets[-1].begin)
+                self.buckets.append(cur)
+            cur.begin = lo
+            cur.layers.append(layer)
+            self._layer_bucket[id(layer)] = cur
+            if cur.end - cur.begin >= limit:
+                cur = None
+        if self.buckets:
+            self.buckets[-1].begin = 0
+        for b in self.buckets:
+            n = (b.end - b.begin) // W
+            assert n * W == b.end - b.begin
+            b.shard_begin = b.begin + self.rank * n
+            b.shard_end = b.shard_begin + n
+            b.shard = torch.empty(n, dtype=torch.float32, device=store.device)
+            b.pending = len(b.layers)
+
+    # ------------------------------------------------------------------ per step
+    def _launch(self, b: _Bucket, store):
+        full = store.flat_grad[b.begin:b.end]
+        if self.world_size == 1 and not self.force:
+            b.shard.copy_(full)
+            b.work = None
+        else:
+            b.work = self._rs(b.shard, full)
+
+    def _rs(self, shard, full):
+        c = self.comm
+        if c.world_size == 1:  # forced single-rank collective
+            import torch.distributed as dist
+            return dist.reduce_scatter_tensor(shard, full, group=c.group, async_op=True) \
+                if c.backend == "nccl" else shard.copy_(full)
+        return c.reduce_scatter_sum(shard, full, async_op=(c.backend == "nccl"))
+
+    def _on_layer_backward(self, layer, model):
+        b = self._layer_bucket.get(id(layer))
+        if b is None:
+            return
+        b.pending -= 1
+        if b.pending == 0:
+            self._launch(b, model.store)
+
+    def apply_gradients(self, model):
+        store = model.store
+        scale = 1.0 / self.world_size if self.average else 1.0
+        gathers = []
+        for b in self.buckets:
+            if b.pending > 0:  # not launched from the backward hook
+                self._launch(b, store)
+            b.pending = len(b.layers)
+        for b in self.buckets:
+            if b.work is not None and hasattr(b.work, "wait"):
+                b.work.wait()
+            b.work = None
+            # owner applies on its shard: var/slots are the flat ranges, the gradient is the reduced shard
+            model.optimizer.apply(_ShardView(store, b), 0, b.shard_end - b.shard_begin, grad_scale=scale,
+                                  grad=b.shard, step=store.global_step)
+            full = store.flat[b.begin:b.end]
+            mine = store.flat[b.shard_begin:b.shard_end]
+            if self.world_size == 1 and not self.force:
+                continue
+            if self.comm.world_size == 1:
+                import torch.distributed as dist
+                if self.comm.backend == "nccl":
+                    gathers.append(dist.all_gather_into_tensor(full, mine, group=self.comm.group, async_op=True))
+                continue
+            w = self.comm.all_gather(full, mine, async_op=(self.comm.backend == "nccl"))
+            if w is not None:
+                gathers.append(w)
+        model.optimizer.finish_step(store)
+        for w in gathers:
+            if hasattr(w, "wait"):
+                w.wait()
+
+    def reduce_stats(self, stats: torch.Tensor) -> torch.Tensor:
+        if self.world_size == 1:
+            return stats
+        s = stats.clone()
+        self.comm.all_reduce_sum(s)
+        return s
+
+
+class _ShardView:
+    """Presents one bucket shard of a VariableStore as a tiny store so ``Optimizer.apply`` runs on it unchanged."""
+
+    def __init__(self, store, bucket: _Bucket):
+        self._store = store
+        self._b = bucket
+        self.flat = store.flat[bucket.shard_begin:bucket.shard_end]
+        self.flat_grad = None
+        self.flat_len = bucket.shard_end - bucket.shard_begin
+        self.global_step = store.global_step
+        self.beta_powers = store.beta_powers
+
+    def slot(self, name: str) -> torch.Tensor:
+        return self._store.slot(name)[self._b.shard_begin:self._b.shard_end]

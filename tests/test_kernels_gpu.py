@@ -1,0 +1,187 @@
+"""HIP kernel numerics against plain PyTorch fp32/fp64 references (needs an MI355X)."""
+import pytest
+import torch
+
+from distributed_tensorflow_amd.ops import functional as F
+from distributed_tensorflow_amd.ops._native import ACT_NONE, ACT_RELU, ACT_SIGMOID
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [  # (M, K, N)
+    (50, 64, 128), (50, 128, 128), (50, 128, 32), (1000, 64, 128), (1000, 128, 32),
+    (256, 784, 128), (4096, 784, 128), (4096, 128, 10), (333, 100, 77), (1, 5, 3), (129, 33, 65),
+    (8192, 128, 128), (70, 784, 10),
+]
+
+
+def _rand(*shape, device, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1).to(device)
+
+
+def _tol(K):
+    return dict(rtol=2e-4, atol=2e-5 * max(K, 16) ** 0.5)
+
+
+@pytest.mark.parametrize("M,K,N", SHAPES)
+@pytest.mark.parametrize("act", [ACT_NONE, ACT_RELU, ACT_SIGMOID])
+def test_dense_forward(gpu_device, M, K, N, act):
+    x, w, b = _rand(M, K, device=gpu_device, seed=1), _rand(K, N, device=gpu_device, seed=2), _rand(N, device=gpu_device, seed=3)
+    y = F.dense_forward(x, w, b, act)
+    ref = x.double() @ w.double() + b.double()
+    ref = torch.relu(ref) if act == ACT_RELU else torch.sigmoid(ref) if act == ACT_SIGMOID else ref
+    torch.testing.assert_close(y, ref.float(), **_tol(K))
+
+
+def test_dense_forward_identity_asymmetric(gpu_device):
+    """A = I with an asymmetric B catches a transposed C-write or a swapped operand map."""
+    n = 128
+    eye = torch.eye(n, device=gpu_device)
+    b = torch.arange(n * n, dtype=torch.float32, device=gpu_device).view(n, n) / 1000.0
+    torch.testing.assert_close(F.dense_forward(eye, b, None, ACT_NONE), b)
+    torch.testing.assert_close(F.dense_forward(b, eye, None, ACT_NONE), b)
+
+
+@pytest.mark.parametrize("M,K,N", SHAPES)
+def test_dense_backward_dx(gpu_device, M, K, N):
+    dz, w = _rand(M, N, device=gpu_device, seed=4), _rand(K, N, device=gpu_device, seed=5)
+    yprev = _rand(M, K, device=gpu_device, seed=6)
+    dx = F.dense_backward_dx(dz, w)
+    ref = (dz.double() @ w.double().t())
+    torch.testing.assert_close(dx, ref.float(), **_tol(N))
+    dx2 = F.dense_backward_dx(dz, w, yprev, ACT_RELU, 1.0 / 0.7)
+    ref2 = torch.where(yprev > 0, ref / 0.7, torch.zeros_like(ref))
+    torch.testing.assert_close(dx2, ref2.float(), **_tol(N))
+    p = torch.sigmoid(yprev)
+    dx3 = F.dense_backward_dx(dz, w, p, ACT_SIGMOID, 1.0)
+    torch.testing.assert_close(dx3, (ref * p.double() * (1 - p.double())).float(), **_tol(N))
+
+
+@pytest.mark.parametrize("M,K,N", SHAPES + [(65536, 784, 128), (20000, 128, 128)])
+def test_dense_backward_dw(gpu_device, M, K, N):
+    x, dz = _rand(M, K, device=gpu_device, seed=7), _rand(M, N, device=gpu_device, seed=8)
+    dw = torch.full((K, N), float("nan"), device=gpu_device)
+    db = torch.full((N,), float("nan"), device=gpu_device)
+    F.dense_backward_dw(x, dz, dw, db)
+    tol = dict(rtol=2e-4, atol=3e-5 * max(M, 16) ** 0.5)
+    torch.testing.assert_close(dw, (x.double().t() @ dz.double()).float(), **tol)
+    torch.testing.assert_close(db, dz.double().sum(0).float(), **tol)
+
+
+def test_fused_dropout_matches_cpu_mask(gpu_device):
+    M, K, N = 300, 64, 128
+    x, w, b = _rand(M, K, device=gpu_device, seed=1), _rand(K, N, device=gpu_device, seed=2), _rand(N, device=gpu_device, seed=3)
+    step = torch.tensor([41], dtype=torch.int64, device=gpu_device)
+    y = F.dense_forward(x, w, b, ACT_RELU, keep=0.7, seed=99, step=step)
+    ref = F.dense_forward(x.cpu(), w.cpu(), b.cpu(), ACT_RELU, keep=0.7, seed=99, step=step.cpu())
+    torch.testing.assert_close(y.cpu(), ref, rtol=2e-4, atol=1e-4)
+    frac = (y == 0).float().mean().item()
+    assert 0.55 < frac < 0.75  # relu kills ~half, dropout 30% of the rest
+    step += 1
+    y2 = F.dense_forward(x, w, b, ACT_RELU, keep=0.7, seed=99, step=step)
+    assert not torch.equal(y, y2)
+
+
+def test_standalone_dropout(gpu_device):
+    x = _rand(1000, 37, device=gpu_device, seed=1) + 2.0
+    step = torch.tensor([7], dtype=torch.int64, device=gpu_device)
+    y = F.dropout(x, 0.7, 5, step)
+    ref = F.dropout(x.cpu(), 0.7, 5, step.cpu())
+    torch.testing.assert_close(y.cpu(), ref)
+    assert abs((y != 0).float().mean().item() - 0.7) < 0.02
+
+
+def test_act_grad_and_activation(gpu_device):
+    dy, y = _rand(513, 77, device=gpu_device, seed=1), _rand(513, 77, device=gpu_device, seed=2)
+    for act in (ACT_RELU, ACT_SIGMOID, ACT_NONE):
+        torch.testing.assert_close(F.act_grad(dy, y, act, 1.3).cpu(), F.act_grad(dy.cpu(), y.cpu(), act, 1.3))
+        torch.testing.assert_close(F.activation_forward(y, act).cpu(), F.activation_forward(y.cpu(), act),
+                                   rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("M,N", [(50, 32), (1000, 32), (4097, 10)])
+@pytest.mark.parametrize("through", [False, True])
+def test_mse_loss(gpu_device, M, N, through):
+    p = torch.sigmoid(_rand(M, N, device=gpu_device, seed=1) * 3)
+    y = (_rand(M, N, device=gpu_device, seed=2) > 0).float()
+    g, st = torch.empty_like(p), F.new_stats(gpu_device)
+    F.mse_loss(p, y, g, None, through, st)
+    gc, sc = torch.empty(M, N), F.new_stats("cpu")
+    F.mse_loss(p.cpu(), y.cpu(), gc, None, through, sc)
+    torch.testing.assert_close(g.cpu(), gc, rtol=1e-5, atol=1e-9)
+    torch.testing.assert_close(st.cpu(), sc, rtol=1e-4, atol=1e-4)
+    # autograd cross-check of the fused gradient
+    pz = p.cpu().double().clone().requires_grad_(True)
+    loss = ((pz - y.cpu().double()) ** 2).mean()
+    loss.backward()
+    ref = pz.grad * (p.cpu().double() * (1 - p.cpu().double()) if through else 1.0)
+    torch.testing.assert_close(g.cpu().double(), ref, rtol=1e-4, atol=1e-10)
+
+
+def test_round_half_to_even(gpu_device):
+    p = torch.tensor([[0.5, 0.5, 0.50001, 0.49999]], device=gpu_device)
+    y = torch.tensor([[0.0, 1.0, 1.0, 0.0]], device=gpu_device)
+    st = F.new_stats(gpu_device)
+    F.mse_loss(p, y, None, None, False, st)
+    assert abs(st[1].item() - 0.75) < 1e-6  # round(0.5) == 0 (half to even), as tf.round
+
+
+@pytest.mark.parametrize("M,C", [(50, 10), (4096, 10), (1000, 37)])
+@pytest.mark.parametrize("sparse", [True, False])
+def test_softmax_xent(gpu_device, M, C, sparse):
+    z = _rand(M, C, device=gpu_device, seed=1) * 4
+    lab = torch.randint(0, C, (M,), generator=torch.Generator().manual_seed(3)).to(gpu_device)
+    labels = lab if sparse else torch.nn.functional.one_hot(lab, C).float()
+    g, st = torch.empty_like(z), F.new_stats(gpu_device)
+    F.softmax_xent(z, labels, g, None, st)
+    zd = z.cpu().double().requires_grad_(True)
+    loss = torch.nn.functional.cross_entropy(zd, lab.cpu(), reduction="mean")
+    loss.backward()
+    torch.testing.assert_close(g.cpu().double(), zd.grad, rtol=1e-4, atol=1e-8)
+    assert abs(st[0].item() / M - loss.item()) < 1e-4 * max(1.0, loss.item())
+    assert abs(st[1].item() - (z.argmax(1) == lab).sum().item()) < 0.5
+    assert st[2].item() == M
+    torch.testing.assert_close(F.softmax(z).cpu(), torch.softmax(z.cpu(), 1), rtol=1e-5, atol=1e-7)
+
+
+def test_adam_tf_formula(gpu_device):
+    n = 10007
+    var, g = _rand(n, device=gpu_device, seed=1), _rand(n, device=gpu_device, seed=2)
+    m, v = torch.zeros(n, device=gpu_device), torch.zeros(n, device=gpu_device)
+    step = torch.zeros(1, dtype=torch.int64, device=gpu_device)
+    pw = torch.ones(2, device=gpu_device)
+    vr, mr, vvr = var.cpu().double(), torch.zeros(n, dtype=torch.double), torch.zeros(n, dtype=torch.double)
+    for t in range(1, 6):
+        F.adam_apply(var, m, v, g, step)
+        F.step_advance(step, pw, 0.9, 0.999)
+        gd = g.cpu().double()
+        lr_t = 1e-3 * (1 - 0.999 ** t) ** 0.5 / (1 - 0.9 ** t)
+        mr = 0.9 * mr + 0.1 * gd
+        vvr = 0.999 * vvr + 0.001 * gd * gd
+        vr = vr - lr_t * mr / (vvr.sqrt() + 1e-8)
+    assert step.item() == 5
+    torch.testing.assert_close(var.cpu().double(), vr, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(pw.cpu(), torch.tensor([0.9 ** 5, 0.999 ** 5]), rtol=1e-5, atol=0)
+
+
+def test_sgd(gpu_device):
+    n = 5003
+    var, g = _rand(n, device=gpu_device, seed=1), _rand(n, device=gpu_device, seed=2)
+    mom = torch.zeros(n, device=gpu_device)
+    ref, refm = var.clone().cpu(), torch.zeros(n)
+    for _ in range(3):
+        F.sgd_apply(var, g, 0.1, mom, 0.9, 0.5)
+        F.sgd_apply(ref, g.cpu(), 0.1, refm, 0.9, 0.5)
+    torch.testing.assert_close(var.cpu(), ref, rtol=1e-5, atol=1e-6)
+    v2, r2 = var.clone(), var.clone().cpu()
+    F.sgd_apply(v2, g, 0.1)
+    F.sgd_apply(r2, g.cpu(), 0.1)
+    torch.testing.assert_close(v2.cpu(), r2, rtol=1e-6, atol=1e-7)
+
+
+def test_xor_generator_matches_cpu(gpu_device):
+    x, y = F.xor_data(5000, 32, 77, gpu_device)
+    xc, yc = F.xor_data(5000, 32, 77, "cpu")
+    assert torch.equal(x.cpu(), xc) and torch.equal(y.cpu(), yc)
+    assert torch.equal(y, (x[:, :32] != x[:, 32:]).float())
+    assert abs(x.mean().item() - 0.5) < 0.01
