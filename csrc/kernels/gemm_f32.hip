@@ -42,7 +42,8 @@ struct GemmArgs {
     int ldy;
     float scale_prev;         // 1/keep of the producing layer's dropout (1 if none)
     // wgrad extras
-    float* colsum;            // [splits][N] partial bias gradients (may be null)
+    float* colsum;            // partial bias gradients of split 0 (may be null)
+    long long colsum_split_stride;  // elements between successive splits' colsum rows
 };
 
 template <int ROWS, bool KC>
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
     }
     if (EPI == EPI_DW) {
         if (do_colsum && tid < BN && (n0 + tid) < p.N)
-            p.colsum[(long long)blockIdx.z * p.N + n0 + tid] = csum;
+            p.colsum[(long long)blockIdx.z * p.colsum_split_stride + n0 + tid] = csum;
     }
 }
 
@@ -267,27 +268,67 @@ int launch_cfg(const GemmArgs& a, int splits, hipStream_t s) {
     return 0;
 }
 
-// Tile choice: the largest tile that still gives every CU a block; N <= 32 uses the
-// narrow tile so thin output layers (10 / 32 columns) do not pay for 128 columns.
-template <bool A_KC, bool B_KC, int EPI>
-int launch_gemm(const GemmArgs& a, int splits, hipStream_t s) {
-    const long long blocks128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128) * splits;
-    if (a.N <= 32) {
-        return launch_cfg<128, 32, 4, 1, A_KC, B_KC, EPI>(a, splits, s);
-    }
-    if (a.N <= 64 || a.M <= 64 || blocks128 < 192) {
-        return launch_cfg<64, 64, 2, 2, A_KC, B_KC, EPI>(a, splits, s);
-    }
-    return launch_cfg<128, 128, 2, 2, A_KC, B_KC, EPI>(a, splits, s);
+// Tile choice: the largest tile that still gives every CU about two co-resident blocks (a block
+// that sits in its LDS-store / barrier phase is covered by the other block's MFMAs); N <= 32
+// uses the narrow tile so thin output layers (10 / 32 columns) do not pay for 128 columns.
+inline long long nblocks(const GemmArgs& a, int bm, int bn, int splits) {
+    return (long long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn) * splits;
 }
 
-__global__ void reduce_slabs_kernel(const float* __restrict__ slabs, long long slab_stride, int splits,
-                                    float* __restrict__ out, long long n) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-         i += (long long)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int k = 0; k < splits; ++k) s += slabs[k * slab_stride + i];
-        out[i] = s;
+template <bool A_KC, bool B_KC, int EPI>
+int launch_gemm(const GemmArgs& a, int splits, hipStream_t s, int tile_hint = 0) {
+    if (a.N <= 32) return launch_cfg<128, 32, 4, 1, A_KC, B_KC, EPI>(a, splits, s);
+    if (tile_hint == 64 || a.N <= 64 || a.M <= 64) return launch_cfg<64, 64, 2, 2, A_KC, B_KC, EPI>(a, splits, s);
+    if (tile_hint == 128) return launch_cfg<128, 128, 2, 2, A_KC, B_KC, EPI>(a, splits, s);
+    if (nblocks(a, 128, 128, splits) >= 1024) return launch_cfg<128, 128, 2, 2, A_KC, B_KC, EPI>(a, splits, s);
+    if (nblocks(a, 64, 128, splits) >= 384) return launch_cfg<64, 128, 2, 2, A_KC, B_KC, EPI>(a, splits, s);
+    return launch_cfg<64, 64, 2, 2, A_KC, B_KC, EPI>(a, splits, s);
+}
+
+// out[i] = sum_s slabs[s * slab_stride + i].  A 1024-thread block covers 64 float4 columns with 16
+// split-groups (one wave each); every thread keeps 4 independent loads in flight, then the 16
+// partial sums meet in LDS.  Element i >= n_main goes to out_tail (the bias gradient that rides
+// behind the weight gradient in every slab).
+__global__ __launch_bounds__(1024) void reduce_slabs_kernel(const float* __restrict__ slabs, long long slab_stride,
+                                                            int splits, float* __restrict__ out_main,
+                                                            long long n_main, float* __restrict__ out_tail,
+                                                            long long n_total) {
+    __shared__ f32x4 part[16][64];
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const long long i4 = (long long)blockIdx.x * 64 + c;   // float4 column
+    const long long i = i4 * 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (i < n_total) {
+        const bool vec = (i + 3 < n_total) && ((slab_stride & 3) == 0);
+        f32x4 a0 = acc, a1 = acc, a2 = acc, a3 = acc;
+        int s = g;
+        if (vec) {
+            for (; s + 48 < splits; s += 64) {
+                a0 += *reinterpret_cast<const f32x4*>(slabs + (long long)s * slab_stride + i);
+                a1 += *reinterpret_cast<const f32x4*>(slabs + (long long)(s + 16) * slab_stride + i);
+                a2 += *reinterpret_cast<const f32x4*>(slabs + (long long)(s + 32) * slab_stride + i);
+                a3 += *reinterpret_cast<const f32x4*>(slabs + (long long)(s + 48) * slab_stride + i);
+            }
+            for (; s < splits; s += 16) a0 += *reinterpret_cast<const f32x4*>(slabs + (long long)s * slab_stride + i);
+        } else {
+            for (; s < splits; s += 16)
+                for (int j = 0; j < 4; ++j)
+                    if (i + j < n_total) a0[j] += slabs[(long long)s * slab_stride + i + j];
+        }
+        acc = (a0 + a1) + (a2 + a3);
+    }
+    part[g][c] = acc;
+    __syncthreads();
+    if (g == 0 && i < n_total) {
+        f32x4 t = part[0][c];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) t += part[k][c];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long long e = i + j;
+            if (e < n_main) out_main[e] = t[j];
+            else if (e < n_total) out_tail[e - n_main] = t[j];
+        }
     }
 }
 
@@ -323,13 +364,20 @@ DTF_API int dtf_dense_bwd_dx(const float* dZ, const float* W, float* dX, int M, 
     return launch_gemm<true, true, EPI_DX>(a, 1, stream);
 }
 
+// wgrad tiling: outputs of at most 128x128 use 64x64 tiles (fewer batch splits for the same
+// number of blocks => less slab traffic); larger ones 128x128 tiles.  About 256-512 blocks.
+static int dw_tile(int N, int K) {
+    if (N <= 32) return 32;
+    return ((long long)K * N <= 128 * 128) ? 64 : 128;
+}
+
 // Number of batch splits the wgrad kernel uses for (M,N,K); the workspace must hold
 // splits * (K*N + N) floats when splits > 1.
 DTF_API int dtf_dense_bwd_dw_splits(int M, int N, int K) {
-    const int tiles = (N <= 32) ? ((K + 127) / 128) * ((N + 31) / 32)
-                                : ((K + 127) / 128) * ((N + 127) / 128);
-    int want = (512 + tiles - 1) / tiles;           // ~2 blocks per CU
-    int max_by_m = (M + 4 * BK - 1) / (4 * BK);      // at least 128 rows of batch per split
+    const int t = dw_tile(N, K);
+    const int tiles = (t == 32) ? ((K + 127) / 128) * ((N + 31) / 32) : ((K + t - 1) / t) * ((N + t - 1) / t);
+    int want = (384 + tiles - 1) / tiles;
+    int max_by_m = (M + 8 * BK - 1) / (8 * BK);      // at least 256 rows of batch per split
     int s = want < max_by_m ? want : max_by_m;
     return s < 1 ? 1 : s;
 }
@@ -339,6 +387,7 @@ DTF_API int dtf_dense_bwd_dw(const float* X, const float* dZ, float* dW, float* 
                              float* workspace, hipStream_t stream) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     const int splits = dtf_dense_bwd_dw_splits(M, N, K);
+    const int hint = dw_tile(N, K);
     GemmArgs a = {};
     a.A = X; a.lda = K;       // A(i=kin, k=m) = X[m*K + kin] -> i-contiguous
     a.B = dZ; a.ldb = N;
@@ -350,22 +399,20 @@ DTF_API int dtf_dense_bwd_dw(const float* X, const float* dZ, float* dW, float* 
     const int eff_splits = (M + chunk - 1) / chunk;
     if (eff_splits <= 1) {
         a.C = dW; a.c_split_stride = 0; a.colsum = db;
-        return launch_gemm<false, false, EPI_DW>(a, 1, stream);
+        return launch_gemm<false, false, EPI_DW>(a, 1, stream, hint);
     }
+    // slab s = [ dW partial (K*N) | db partial (N) ], rows padded to a multiple of 4 floats
     const long long kn = (long long)K * N;
-    a.C = workspace; a.c_split_stride = kn;
-    a.colsum = db ? workspace + (long long)eff_splits * kn : nullptr;
-    int rc = launch_gemm<false, false, EPI_DW>(a, eff_splits, stream);
+    const long long stride = ((kn + N + 3) / 4) * 4;
+    a.C = workspace; a.c_split_stride = stride;
+    a.colsum = db ? workspace + kn : nullptr;
+    a.colsum_split_stride = stride;
+    int rc = launch_gemm<false, false, EPI_DW>(a, eff_splits, stream, hint);
     if (rc) return rc;
-    int blocks = (int)((kn / 4 + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, stream, workspace, kn, eff_splits, dW, kn);
+    const long long n_total = db ? kn + N : kn;
+    const int blocks = (int)((n_total + 255) / 256);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(1024), 0, stream, workspace, stride, eff_splits, dW,
+                       kn, db, n_total);
     DTF_CHECK_LAUNCH();
-    if (db) {
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3((N + 255) / 256), dim3(256), 0, stream,
-                           workspace + (long long)eff_splits * kn, (long long)N, eff_splits, db, (long long)N);
-        DTF_CHECK_LAUNCH();
-    }
     return 0;
 }

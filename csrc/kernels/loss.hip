@@ -41,90 +41,122 @@ __device__ __forceinline__ void block_add3(float a, float b, float c, float* sta
     }
 }
 
-// One thread per example row (N is a classifier/bit-vector width: tens of columns).
-// P are probabilities (the dense layer already applied the sigmoid).  Writes
-// G = dLoss/dP * (P (1-P) if through_sigmoid) for Loss = mean_{M,N} (P - Y)^2.
-__global__ __launch_bounds__(256) void mse_rows_kernel(const float* __restrict__ P, const float* __restrict__ Y,
-                                                       float* __restrict__ G, int M, int N, float grad_scale,
-                                                       int through_sigmoid, float* stats) {
+// Elementwise over the flat [M*N] range, 16 bytes per lane.  P are probabilities (the dense
+// layer already applied the sigmoid).  G = dLoss/dP * (P (1-P) if through_sigmoid) for
+// Loss = mean_{M,N} (P - Y)^2.  Each element carries weight 1/N into the per-example sums.
+__global__ __launch_bounds__(256) void mse_flat_kernel(const float* __restrict__ P, const float* __restrict__ Y,
+                                                       float* __restrict__ G, long long total, float inv_n,
+                                                       float grad_scale, int through_sigmoid, float* stats) {
     float loss = 0.f, acc = 0.f, cnt = 0.f;
-    const float inv_n = 1.0f / (float)N;
-    for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < M; row += gridDim.x * blockDim.x) {
-        const float* p = P + (long long)row * N;
-        const float* y = Y + (long long)row * N;
-        float l = 0.f, a = 0.f;
-        for (int j = 0; j < N; ++j) {
-            const float pj = p[j], d = pj - y[j];
-            l += d * d;
-            a += (rintf(pj) == rintf(y[j])) ? 1.f : 0.f;
-            if (G) {
-                float g = 2.0f * d * grad_scale;
-                if (through_sigmoid) g *= pj * (1.0f - pj);
-                G[(long long)row * N + j] = g;
-            }
+    const long long n4 = total >> 2;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const f32x4* P4 = reinterpret_cast<const f32x4*>(P);
+    const f32x4* Y4 = reinterpret_cast<const f32x4*>(Y);
+    f32x4* G4 = reinterpret_cast<f32x4*>(G);
+    for (long long i = tid; i < n4; i += stride) {
+        const f32x4 p = P4[i], y = Y4[i];
+        f32x4 g;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float d = p[j] - y[j];
+            loss += d * d;
+            acc += (rintf(p[j]) == rintf(y[j])) ? 1.f : 0.f;
+            float gj = 2.0f * d * grad_scale;
+            if (through_sigmoid) gj *= p[j] * (1.0f - p[j]);
+            g[j] = gj;
         }
-        loss += l * inv_n;
-        acc += a * inv_n;
-        cnt += 1.f;
+        cnt += 4.f;
+        if (G) G4[i] = g;
     }
-    if (stats) block_add3(loss, acc, cnt, stats);
+    for (long long i = (n4 << 2) + tid; i < total; i += stride) {
+        const float p = P[i], d = p - Y[i];
+        loss += d * d;
+        acc += (rintf(p) == rintf(Y[i])) ? 1.f : 0.f;
+        cnt += 1.f;
+        if (G) {
+            float gj = 2.0f * d * grad_scale;
+            if (through_sigmoid) gj *= p * (1.0f - p);
+            G[i] = gj;
+        }
+    }
+    if (stats) block_add3(loss * inv_n, acc * inv_n, cnt * inv_n, stats);
 }
 
-// One thread per row.  labels: int64 class ids (sparse) or one-hot/probability rows (dense).
+// Softmax cross-entropy, 256 rows per block.  The [256, C] logit tile is staged through LDS
+// with coalesced loads (row stride C+1 floats, so the per-row walk is bank-conflict free), each
+// thread then owns one row, and the gradient tile leaves through LDS with coalesced stores.
+// labels: int64 class ids (sparse) or one-hot / probability rows (dense).
 __global__ __launch_bounds__(256) void softmax_xent_kernel(const float* __restrict__ Z,
                                                            const long long* __restrict__ sparse_labels,
                                                            const float* __restrict__ dense_labels,
                                                            float* __restrict__ G, int M, int C, float grad_scale,
                                                            float* stats) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];   // [256][C+1] logits (+ [256][C+1] dense labels)
+    const int ld = C + 1;
+    float* zt = tile;
+    float* yt = tile + 256 * ld;
     float loss = 0.f, acc = 0.f, cnt = 0.f;
-    for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < M; row += gridDim.x * blockDim.x) {
-        const float* z = Z + (long long)row * C;
-        float mx = z[0];
-        int arg = 0;
-        for (int j = 1; j < C; ++j) {
-            const float v = z[j];
-            if (v > mx) {
-                mx = v;
-                arg = j;
+    const int tid = threadIdx.x;
+    for (long long row0 = (long long)blockIdx.x * 256; row0 < M; row0 += (long long)gridDim.x * 256) {
+        const int rows = (int)min((long long)256, M - row0);
+        const int elems = rows * C;
+        const float* zsrc = Z + row0 * C;
+        for (int e = tid; e < elems; e += 256) {
+            const int r = e / C, c = e - r * C;
+            zt[r * ld + c] = zsrc[e];
+            if (dense_labels) yt[r * ld + c] = dense_labels[row0 * C + e];
+        }
+        __syncthreads();
+        if (tid < rows) {
+            float* z = zt + tid * ld;
+            float mx = z[0];
+            int arg = 0;
+            for (int j = 1; j < C; ++j) {
+                const float v = z[j];
+                if (v > mx) {
+                    mx = v;
+                    arg = j;
+                }
+            }
+            float se = 0.f;
+            for (int j = 0; j < C; ++j) se += __expf(z[j] - mx);
+            const float lse = mx + __logf(se);
+            const float inv = 1.0f / se;
+            float l = 0.f;
+            int label_arg = 0;
+            if (sparse_labels) {
+                label_arg = (int)sparse_labels[row0 + tid];
+                l = lse - z[label_arg];
+                for (int j = 0; j < C; ++j)
+                    z[j] = (__expf(z[j] - mx) * inv - (j == label_arg ? 1.f : 0.f)) * grad_scale;
+            } else {
+                const float* y = yt + tid * ld;
+                float ymax = y[0], ysum = 0.f;
+                for (int j = 0; j < C; ++j) {
+                    const float yj = y[j];
+                    if (yj > ymax) {
+                        ymax = yj;
+                        label_arg = j;
+                    }
+                    ysum += yj;
+                    l += yj * (lse - z[j]);
+                }
+                for (int j = 0; j < C; ++j) z[j] = (__expf(z[j] - mx) * inv * ysum - y[j]) * grad_scale;
+            }
+            loss += l;
+            acc += (arg == label_arg) ? 1.f : 0.f;
+            cnt += 1.f;
+        }
+        __syncthreads();
+        if (G) {
+            float* gdst = G + row0 * C;
+            for (int e = tid; e < elems; e += 256) {
+                const int r = e / C, c = e - r * C;
+                gdst[e] = zt[r * ld + c];
             }
         }
-        float se = 0.f;
-        for (int j = 0; j < C; ++j) se += __expf(z[j] - mx);
-        const float lse = mx + __logf(se);
-        const float inv = 1.0f / se;
-        float l = 0.f;
-        int label_arg = 0;
-        if (sparse_labels) {
-            label_arg = (int)sparse_labels[row];
-            l = lse - z[label_arg];
-            if (G) {
-                for (int j = 0; j < C; ++j) {
-                    const float sm = __expf(z[j] - mx) * inv;
-                    G[(long long)row * C + j] = (sm - (j == label_arg ? 1.f : 0.f)) * grad_scale;
-                }
-            }
-        } else {
-            const float* y = dense_labels + (long long)row * C;
-            float ymax = y[0], ysum = 0.f;
-            for (int j = 0; j < C; ++j) {
-                const float yj = y[j];
-                if (yj > ymax) {
-                    ymax = yj;
-                    label_arg = j;
-                }
-                ysum += yj;
-                l += yj * (lse - z[j]);
-            }
-            if (G) {
-                for (int j = 0; j < C; ++j) {
-                    const float sm = __expf(z[j] - mx) * inv;
-                    G[(long long)row * C + j] = (sm * ysum - y[j]) * grad_scale;
-                }
-            }
-        }
-        loss += l;
-        acc += (arg == label_arg) ? 1.f : 0.f;
-        cnt += 1.f;
+        __syncthreads();
     }
     if (stats) block_add3(loss, acc, cnt, stats);
 }
@@ -174,8 +206,12 @@ inline int row_grid(int M) {
 DTF_API int dtf_mse_loss(const float* P, const float* Y, float* G, int M, int N, float grad_scale,
                          int through_sigmoid, float* stats, hipStream_t stream) {
     if (M <= 0 || N <= 0) return 0;
-    hipLaunchKernelGGL(mse_rows_kernel, dim3(row_grid(M)), dim3(256), 0, stream, P, Y, G, M, N, grad_scale,
-                       through_sigmoid, stats);
+    const long long total = (long long)M * N;
+    long long g = (total / 4 + 255) / 256;
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(mse_flat_kernel, dim3((int)g), dim3(256), 0, stream, P, Y, G, total, 1.0f / (float)N,
+                       grad_scale, through_sigmoid, stats);
     DTF_CHECK_LAUNCH();
     return 0;
 }
@@ -183,7 +219,14 @@ DTF_API int dtf_mse_loss(const float* P, const float* Y, float* G, int M, int N,
 DTF_API int dtf_softmax_xent(const float* Z, const long long* sparse_labels, const float* dense_labels, float* G,
                              int M, int C, float grad_scale, float* stats, hipStream_t stream) {
     if (M <= 0 || C <= 0) return 0;
-    hipLaunchKernelGGL(softmax_xent_kernel, dim3(row_grid(M)), dim3(256), 0, stream, Z, sparse_labels,
+    const size_t lds = (size_t)256 * (C + 1) * sizeof(float) * (dense_labels ? 2 : 1);
+    if (lds > 150 * 1024) return -3;  // class count beyond what one block stages (about 70 dense / 145 sparse)
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(softmax_xent_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(softmax_xent_kernel, dim3(row_grid(M)), dim3(256), lds, stream, Z, sparse_labels,
                        dense_labels, G, M, C, grad_scale, stats);
     DTF_CHECK_LAUNCH();
     return 0;

@@ -131,7 +131,7 @@ def dense_dw_workspace_floats(M: int, N: int, K: int) -> int:
     if not nv.kernels_available():
         return 0
     s = nv.kernels().dtf_dense_bwd_dw_splits(M, N, K)
-    return s * (K * N + N) if s > 1 else 0
+    return s * ((K * N + N + 3) // 4 * 4) if s > 1 else 0
 
 
 def dense_backward_dw(x, dz, dw, db=None, workspace=None):
