@@ -9,12 +9,22 @@
 //   wgrad     dW[K,N] = X[M,K]^T . dZ[M,N],  db[N] = colsum(dZ)     A m-contig, B n-contig
 //
 // Block = 256 threads = 4 waves; each wave owns a TMxTN grid of 32x32 MFMA tiles.
-// K is consumed in 32-deep LDS tiles.  Inside each group of 8 k-values the lane half
-// h = lane>>5 takes k = 8*kk + 4*h + t at MFMA step t: a GEMM sums over k in any
-// order, and this order lets a k-contiguous operand be fetched with one 16-byte
-// ds_read_b128 per four MFMAs.  Row stride of k-contiguous LDS tiles is 36 floats
-// (144 B = 9 x 16 B, odd multiple), which makes those b128 reads conflict-free.
+// K is consumed in 32-deep tiles through a double-buffered LDS image: the global loads of
+// tile t+1 are issued before the MFMAs of tile t, land in registers meanwhile, and are
+// written to the other LDS buffer afterwards, so one barrier per tile suffices.
+//
+// Global loads are raw buffer loads: an out-of-range lane gets an out-of-range offset and
+// the hardware returns zeros, so tails need no branches (a branchy loader made hipcc wait
+// for vmcnt(0) in front of the MFMAs).
+//
+// Inside each group of 8 k-values the lane half h = lane>>5 takes k = 8*kk + 4*h + t at
+// MFMA step t: a GEMM sums over k in any order, and this order lets a k-contiguous operand
+// be fetched with one 16-byte ds_read_b128 per four MFMAs.  Row stride of k-contiguous LDS
+// tiles is 36 floats (144 B = 9 x 16 B, an odd multiple), which makes those reads
+// conflict-free.
 #include "common.h"
+
+#include <cstdlib>
 
 namespace {
 
@@ -44,70 +54,87 @@ struct GemmArgs {
     // wgrad extras
     float* colsum;            // partial bias gradients of split 0 (may be null)
     long long colsum_split_stride;  // elements between successive splits' colsum rows
+    int dbg;                  // timing-only ablation bits (DTF_GEMM_DBG); 0 in production
 };
 
+typedef unsigned int u32x4 __attribute__((vector_size(16)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, long long bytes) {
+    const unsigned n = bytes <= 0 ? 0u : (bytes > 0xFFFFFFF0ll ? 0xFFFFFFF0u : (unsigned)bytes);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)n, 0x00020000);
+}
+
+constexpr unsigned OOB = 0xFFFFFFF8u;  // >= any num_records: the load returns zeros
+
+// Tile of ROWS (M- or N-dim) x BK (k-dim) held by 256 threads as NV float4 each.
+//   KC  (k is the contiguous global dim): LDS image [ROWS][LDK]
+//   !KC (the M/N index is contiguous)   : LDS image [BK][ROWS+4]
 template <int ROWS, bool KC>
 struct TileLoader {
-    // Tile of ROWS (M- or N-dim) x BK (k-dim).  KC: k is the contiguous global dim.
     static constexpr int NV = ROWS * BK / 4 / 256;
-    static constexpr int LD = KC ? LDK : (ROWS + 4);
     static constexpr int LDS_FLOATS = KC ? ROWS * LDK : BK * (ROWS + 4);
 
+    __amdgpu_buffer_rsrc_t rsrc;
+    int ld;
+    int mn_left;   // valid rows/cols of the M/N dimension from this block's origin
     f32x4 v[NV];
 
-    __device__ __forceinline__ void load(const float* __restrict__ base, int ld, int mn0, int mn_dim,
-                                         int k0, int k_end, bool vec_ok, int tid) {
-#pragma unroll
-        for (int s = 0; s < NV; ++s) {
-            const int id = tid + 256 * s;
-            int r, c;  // r: index along mn, c: index along k (both tile-local)
-            if (KC) {
-                r = id >> 3;
-                c = (id & 7) * 4;
-            } else {
-                c = id / (ROWS / 4);
-                r = (id % (ROWS / 4)) * 4;
-            }
-            const int gm = mn0 + r, gk = k0 + c;
-            f32x4 x = {0.f, 0.f, 0.f, 0.f};
-            if (KC) {
-                if (gm < mn_dim) {
-                    const float* p = base + (long long)gm * ld + gk;
-                    if (vec_ok && gk + 3 < k_end) {
-                        x = *reinterpret_cast<const f32x4*>(p);
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (gk + j < k_end) x[j] = p[j];
-                    }
-                }
-            } else {
-                if (gk < k_end) {
-                    const float* p = base + (long long)gk * ld + gm;
-                    if (vec_ok && gm + 3 < mn_dim) {
-                        x = *reinterpret_cast<const f32x4*>(p);
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (gm + j < mn_dim) x[j] = p[j];
-                    }
-                }
-            }
-            v[s] = x;
+    // base points at element (mn0, kbeg) of the operand; rows_total/k_total bound the allocation
+    __device__ __forceinline__ void init(const float* base, int ld_, int mn0, int mn_dim, int kbeg, int k_total) {
+        ld = ld_;
+        mn_left = mn_dim - mn0;
+        if (KC) {
+            // rows = mn index: base + mn0*ld ; buffer ends after row mn_dim-1
+            rsrc = make_rsrc(base + (long long)mn0 * ld, ((long long)mn_left * ld) * 4);
+        } else {
+            // rows = k index: base + kbeg*ld + mn0 ; buffer ends after row k_total-1
+            rsrc = make_rsrc(base + (long long)kbeg * ld + mn0, (((long long)(k_total - kbeg)) * ld - mn0) * 4);
         }
     }
 
-    __device__ __forceinline__ void store(float* lds, int tid) const {
+    // Issue the tile's loads (k0: absolute k of the tile start; k_left = kend - k0).  Nothing here
+    // consumes the data, so the wait lands in store(), after the MFMAs of the previous tile.
+    __device__ __forceinline__ void load(int k0, int kbeg, int k_left, int tid) {
 #pragma unroll
         for (int s = 0; s < NV; ++s) {
             const int id = tid + 256 * s;
-            int off;
+            unsigned off;
+            bool ok;
+            if (KC) {
+                const int r = id >> 3;            // mn index
+                const int c = (id & 7) * 4;       // k index
+                off = ((unsigned)r * (unsigned)ld + (unsigned)(k0 + c)) * 4u;
+                ok = (r < mn_left) && (c < k_left);
+            } else {
+                const int c = id / (ROWS / 4);         // k index
+                const int r = (id % (ROWS / 4)) * 4;   // mn index
+                off = ((unsigned)(k0 - kbeg + c) * (unsigned)ld + (unsigned)r) * 4u;
+                ok = (c < k_left) && (r < mn_left);
+            }
+            // whole-vector bit_cast only: indexing the builtin's result element-wise makes hipcc
+            // (ROCm 7.2) emit a single-dword load
+            const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(ok ? off : OOB), 0, 0);
+            v[s] = __builtin_bit_cast(f32x4, raw);
+        }
+    }
+
+    // Zero the elements past the K (or M/N) tail of a partially valid vector and write the LDS image.
+    __device__ __forceinline__ void store(float* lds, int k_left, int tid) const {
+#pragma unroll
+        for (int s = 0; s < NV; ++s) {
+            const int id = tid + 256 * s;
+            int off, lim;
             if (KC) {
                 off = (id >> 3) * LDK + (id & 7) * 4;
+                lim = k_left - (id & 7) * 4;
             } else {
                 off = (id / (ROWS / 4)) * (ROWS + 4) + (id % (ROWS / 4)) * 4;
+                lim = mn_left - (id % (ROWS / 4)) * 4;
             }
-            *reinterpret_cast<f32x4*>(lds + off) = v[s];
+            f32x4 x = v[s];
+#pragma unroll
+            for (int j = 1; j < 4; ++j) x[j] = (j < lim) ? x[j] : 0.f;
+            *reinterpret_cast<f32x4*>(lds + off) = x;
         }
     }
 };
@@ -136,10 +163,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
     static_assert(TM >= 1 && TN >= 1, "wave tile must hold one 32x32 MFMA tile");
     using LoadA = TileLoader<BM, A_KC>;
     using LoadB = TileLoader<BN, B_KC>;
+    constexpr int STAGE = LoadA::LDS_FLOATS + LoadB::LDS_FLOATS;
 
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;
-    float* Bs = smem + LoadA::LDS_FLOATS;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // two stages of [A tile | B tile]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -151,9 +177,6 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
     const int n0 = blockIdx.x * BN;
     const int kbeg = blockIdx.z * p.k_chunk;
     const int kend = min(p.K, kbeg + p.k_chunk);
-
-    const bool a_vec = ((p.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.A) & 15) == 0);
-    const bool b_vec = ((p.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.B) & 15) == 0);
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -168,33 +191,45 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
 
     LoadA la;
     LoadB lb;
-    la.load(p.A, p.lda, m0, p.M, kbeg, kend, a_vec, tid);
-    lb.load(p.B, p.ldb, n0, p.N, kbeg, kend, b_vec, tid);
-    la.store(As, tid);
-    lb.store(Bs, tid);
+    la.init(p.A, p.lda, m0, p.M, kbeg, p.K);
+    lb.init(p.B, p.ldb, n0, p.N, kbeg, p.K);
+    la.load(kbeg, kbeg, kend - kbeg, tid);
+    lb.load(kbeg, kbeg, kend - kbeg, tid);
+    la.store(smem, kend - kbeg, tid);
+    lb.store(smem + LoadA::LDS_FLOATS, kend - kbeg, tid);
     __syncthreads();
 
+    unsigned long long dbg_t0 = 0, dbg_r0 = 0;
+    if (p.dbg & 8) { dbg_t0 = __builtin_amdgcn_s_memtime(); dbg_r0 = __builtin_amdgcn_s_memrealtime(); }
+    int stage = 0;
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         const bool more = (k0 + BK) < kend;
-        if (more) {
-            la.load(p.A, p.lda, m0, p.M, k0 + BK, kend, a_vec, tid);
-            lb.load(p.B, p.ldb, n0, p.N, k0 + BK, kend, b_vec, tid);
+        const float* As = smem + stage * STAGE;
+        const float* Bs = As + LoadA::LDS_FLOATS;
+        if (more && !(p.dbg & 1)) {
+            la.load(k0 + BK, kbeg, kend - k0 - BK, tid);
+            lb.load(k0 + BK, kbeg, kend - k0 - BK, tid);
         }
+        // All fragments of the 32-deep tile are fetched up front (16*(TM+TN) registers): the LDS
+        // reads issue back to back and the MFMAs drain them with counted waits, instead of every
+        // MFMA pair paying the latency of a read issued just before it.
+        f32x4 a[BK / 8][TM], b[BK / 8][TN];
 #pragma unroll
         for (int kk = 0; kk < BK / 8; ++kk) {
-            f32x4 a[TM], b[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = read_frag<BM, A_KC>(As, (wm * TM + i) * 32 + li, kk, h);
+            for (int i = 0; i < TM; ++i) a[kk][i] = read_frag<BM, A_KC>(As, (wm * TM + i) * 32 + li, kk, h);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = read_frag<BN, B_KC>(Bs, (wn * TN + j) * 32 + li, kk, h);
+            for (int j = 0; j < TN; ++j) b[kk][j] = read_frag<BN, B_KC>(Bs, (wn * TN + j) * 32 + li, kk, h);
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk)
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
-        }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][i][t], b[kk][j][t], acc[i][j], 0, 0, 0);
         if (EPI == EPI_DW) {
             if (do_colsum && tid < BN) {
                 // B tile is n-contiguous here: Bs[k][n].  Rows past kend were staged as zeros.
@@ -202,12 +237,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
                 for (int k = 0; k < BK; ++k) csum += Bs[k * (BN + 4) + tid];
             }
         }
-        __syncthreads();
-        if (more) {
-            la.store(As, tid);
-            lb.store(Bs, tid);
-            __syncthreads();
+        if (more && !(p.dbg & 2)) {
+            float* nxt = smem + (stage ^ 1) * STAGE;
+            la.store(nxt, kend - k0 - BK, tid);
+            lb.store(nxt + LoadA::LDS_FLOATS, kend - k0 - BK, tid);
         }
+        if (!(p.dbg & 4)) __syncthreads();
+        stage ^= 1;
     }
 
     // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -251,19 +287,44 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
             }
         }
     }
+    if ((p.dbg & 8) && tid == 0) {   // timing-only diagnostic: loop cycles and 100 MHz ticks into the tile's first row
+        C[(long long)m0 * p.ldc + n0] = (float)(__builtin_amdgcn_s_memtime() - dbg_t0);
+        C[(long long)m0 * p.ldc + n0 + 1] = (float)(__builtin_amdgcn_s_memrealtime() - dbg_r0);
+    }
     if (EPI == EPI_DW) {
         if (do_colsum && tid < BN && (n0 + tid) < p.N)
             p.colsum[(long long)blockIdx.z * p.colsum_split_stride + n0 + tid] = csum;
     }
 }
 
+inline int env_dbg() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("DTF_GEMM_DBG");
+        v = e ? atoi(e) : 0;
+    }
+    return v;
+}
+
 template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int EPI>
 int launch_cfg(const GemmArgs& a, int splits, hipStream_t s) {
     using LoadA = TileLoader<BM, A_KC>;
     using LoadB = TileLoader<BN, B_KC>;
-    const size_t lds = (LoadA::LDS_FLOATS + LoadB::LDS_FLOATS) * sizeof(float);
+    const size_t lds = 2 * (LoadA::LDS_FLOATS + LoadB::LDS_FLOATS) * sizeof(float);
+    auto kern = gemm_f32_kernel<BM, BN, WM, WN, A_KC, B_KC, EPI>;
+    if (lds > 48 * 1024) {
+        static bool once = false;  // per instantiation
+        if (!once) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+            once = true;
+        }
+    }
     dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, splits);
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, A_KC, B_KC, EPI>), grid, dim3(256), lds, s, a);
+    GemmArgs args = a;
+    args.dbg = env_dbg();
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, args);
     DTF_CHECK_LAUNCH();
     return 0;
 }
@@ -275,8 +336,20 @@ inline long long nblocks(const GemmArgs& a, int bm, int bn, int splits) {
     return (long long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn) * splits;
 }
 
+inline int env_tile() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("DTF_GEMM_TILE");   // tuning aid: 64 / 128 / 6428 (=64x128) forces a tile
+        v = e ? atoi(e) : 0;
+    }
+    return v;
+}
+
 template <bool A_KC, bool B_KC, int EPI>
 int launch_gemm(const GemmArgs& a, int splits, hipStream_t s, int tile_hint = 0) {
+    if (a.N > 32 && env_tile() == 6428) return launch_cfg<64, 128, 2, 2, A_KC, B_KC, EPI>(a, splits, s);
+    if (a.N > 32 && env_tile() == 128) return launch_cfg<128, 128, 2, 2, A_KC, B_KC, EPI>(a, splits, s);
+    if (a.N > 32 && env_tile() == 64) return launch_cfg<64, 64, 2, 2, A_KC, B_KC, EPI>(a, splits, s);
     if (a.N <= 32) return launch_cfg<128, 32, 4, 1, A_KC, B_KC, EPI>(a, splits, s);
     if (tile_hint == 64 || a.N <= 64 || a.M <= 64) return launch_cfg<64, 64, 2, 2, A_KC, B_KC, EPI>(a, splits, s);
     if (tile_hint == 128) return launch_cfg<128, 128, 2, 2, A_KC, B_KC, EPI>(a, splits, s);
@@ -365,18 +438,19 @@ DTF_API int dtf_dense_bwd_dx(const float* dZ, const float* W, float* dX, int M, 
 }
 
 // wgrad tiling: outputs of at most 128x128 use 64x64 tiles (fewer batch splits for the same
-// number of blocks => less slab traffic); larger ones 128x128 tiles.  About 256-512 blocks.
+// number of blocks => less slab traffic); larger ones 128x128 tiles.  About two blocks per CU.
 static int dw_tile(int N, int K) {
     if (N <= 32) return 32;
     return ((long long)K * N <= 128 * 128) ? 64 : 128;
 }
 
 // Number of batch splits the wgrad kernel uses for (M,N,K); the workspace must hold
-// splits * (K*N + N) floats when splits > 1.
+// splits * round_up(K*N + N, 4) floats when splits > 1.
 DTF_API int dtf_dense_bwd_dw_splits(int M, int N, int K) {
     const int t = dw_tile(N, K);
     const int tiles = (t == 32) ? ((K + 127) / 128) * ((N + 31) / 32) : ((K + t - 1) / t) * ((N + t - 1) / t);
-    int want = (384 + tiles - 1) / tiles;
+    int want = 512 / tiles;                           // floor: at most two blocks per CU
+    if (want < 1) want = 1;
     int max_by_m = (M + 8 * BK - 1) / (8 * BK);      // at least 256 rows of batch per split
     int s = want < max_by_m ? want : max_by_m;
     return s < 1 ? 1 : s;

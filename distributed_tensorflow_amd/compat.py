@@ -1,0 +1,580 @@
+"""Graph-style (TensorFlow-1.x-shaped) front end.
+
+Lets a script written like /root/reference/example.py run almost unchanged::
+
+    from distributed_tensorflow_amd import compat as tf
+    from distributed_tensorflow_amd.compat import keras
+
+    with tf.device(device):
+        input_ = tf.placeholder(tf.float32, shape=(None, 64))
+        x = keras.layers.Dense(128, activation='relu')(input_)
+        ...
+        loss = tf.reduce_mean(keras.losses.mean_squared_error(labels, preds))
+        train_step = tf.train.AdamOptimizer().minimize(loss, global_step=global_step)
+    with tf.train.MonitoredTrainingSession(master=target, is_chief=..., checkpoint_dir=..., hooks=hooks) as sess:
+        sess.run([accuracy, loss, summ, train_step], feed_dict={input_: bx, labels: by, K.learning_phase(): 1})
+
+There is no tracing compiler behind this: symbolic nodes only *describe* the model.  On the
+first session the graph is lowered once onto the kernel-launch engine - the chain of layer
+nodes becomes a :class:`~distributed_tensorflow_amd.models.Sequential`, the loss expression is
+matched to a fused loss kernel, the accuracy expression to the metric the same kernel
+produces - and ``sess.run`` of the training op is the same fixed sequence of HIP kernel
+launches as ``model.train_step``.  Other expressions (``tf.round``, ``tf.equal``...) are
+evaluated eagerly for fetches that are not on the training path.
+"""
+from __future__ import annotations
+
+import contextlib
+import types
+from typing import Any, Dict, List, Optional, Sequence
+
+import torch
+
+from . import callbacks as _callbacks
+from . import cluster as _cluster
+from . import flags as _flags
+from . import layers as _layers
+from . import losses as _losses
+from . import optimizers as _optimizers
+from . import saver as _saver
+from . import session as _session
+from . import summary as _summary
+from .engine import ACCURACY, GLOBAL_STEP, LOSS, TRAIN_OP, ModelEngine
+from .models.sequential import Sequential as _Sequential
+from .models.sequential import _as_tensor
+
+float32 = torch.float32
+float64 = torch.float64
+int32 = torch.int32
+int64 = torch.int64
+bool_ = torch.bool
+_DTYPES = {"float": torch.float32, "float32": torch.float32, "int32": torch.int32, "int64": torch.int64,
+           "bool": torch.bool}
+
+
+# --------------------------------------------------------------------------- symbolic nodes
+class Tensor:
+    """A symbolic value.  ``op`` names how it is computed from ``inputs``."""
+
+    def __init__(self, op: str, inputs: Sequence[Any] = (), attrs: Optional[dict] = None, name: Optional[str] = None,
+                 shape=None, graph: Optional["Graph"] = None):
+        self.op = op
+        self.inputs = list(inputs)
+        self.attrs = dict(attrs or {})
+        self.graph = graph or get_default_graph()
+        self.name = self.graph.unique_name(name or op)
+        self.shape = shape
+        self.device = self.graph.current_device(op)
+        self.graph.nodes.append(self)
+
+    def eval(self, feed_dict=None, session=None):
+        """``Tensor.eval`` (/root/reference/example.py:225): sugar for ``session.run(self, feed_dict)``."""
+        sess = session or _default_session()
+        if sess is None:
+            raise ValueError("no session: pass session= or enter one with `with sess:`")
+        return sess.run(self, feed_dict)
+
+    def __repr__(self):
+        return "<Tensor %r op=%s>" % (self.name, self.op)
+
+    __hash__ = object.__hash__
+
+    # arithmetic sugar
+    def __sub__(self, o): return Tensor("sub", [self, o])
+    def __add__(self, o): return Tensor("add", [self, o])
+    def __mul__(self, o): return Tensor("mul", [self, o])
+    def __truediv__(self, o): return Tensor("div", [self, o])
+
+
+class Operation(Tensor):
+    """A node run for its effect (training op, initializer); fetching it yields ``None``."""
+
+
+class VariableNode(Tensor):
+    """``tf.Variable``: only non-trainable scalars are created by scripts (``global_step``)."""
+
+    def __init__(self, initial_value, dtype=None, name=None, trainable=True):
+        super().__init__("Variable", [], {"initial_value": initial_value, "dtype": dtype, "trainable": trainable},
+                         name=name or "Variable")
+
+
+class Graph:
+    def __init__(self):
+        self.nodes: List[Tensor] = []
+        self._names: Dict[str, int] = {}
+        self._device_stack: List[Any] = []
+        self._scope: List[str] = []
+        self._engine: Optional["GraphEngine"] = None
+        self.finalized = False
+        self.learning_phase: Optional[Tensor] = None
+        self.device_setter = None
+
+    def unique_name(self, base: str) -> str:
+        full = "/".join(self._scope + [base])
+        n = self._names.get(full, 0)
+        self._names[full] = n + 1
+        return full if n == 0 else "%s_%d" % (full, n)
+
+    def current_device(self, op: str) -> Optional[str]:
+        if not self._device_stack:
+            return None
+        d = self._device_stack[-1]
+        if isinstance(d, _cluster.DeviceSetter):
+            return d("Variable" if op == "Variable" else "op")
+        return d if isinstance(d, str) else None
+
+    def as_graph_def(self) -> dict:
+        return {"nodes": [{"name": n.name, "op": n.op, "device": n.device,
+                           "inputs": [i.name for i in n.inputs if isinstance(i, Tensor)]} for n in self.nodes]}
+
+    def get_config(self):
+        return self.as_graph_def()
+
+    def engine(self) -> "GraphEngine":
+        if self._engine is None:
+            self._engine = GraphEngine(self)
+        return self._engine
+
+    def finalize(self):
+        self.finalized = True
+
+
+_default_graph = Graph()
+_session_stack: List[Any] = []
+
+
+def get_default_graph() -> Graph:
+    return _default_graph
+
+
+def reset_default_graph():
+    global _default_graph
+    _default_graph = Graph()
+    _summary.reset_collection()
+    return _default_graph
+
+
+def _default_session():
+    return _session_stack[-1] if _session_stack else _KerasBackend._session
+
+
+@contextlib.contextmanager
+def device(device_name_or_function):
+    """``tf.device``: records the device function; variable nodes get ``/job:ps/task:k`` strings from a
+    ``replica_device_setter`` and the setter's cluster decides the training strategy."""
+    g = get_default_graph()
+    if isinstance(device_name_or_function, _cluster.DeviceSetter):
+        g.device_setter = device_name_or_function
+    g._device_stack.append(device_name_or_function)
+    try:
+        yield
+    finally:
+        g._device_stack.pop()
+
+
+@contextlib.contextmanager
+def name_scope(name: str):
+    g = get_default_graph()
+    g._scope.append(name)
+    try:
+        yield name
+    finally:
+        g._scope.pop()
+
+
+def placeholder(dtype=float32, shape=None, name=None) -> Tensor:
+    return Tensor("Placeholder", [], {"dtype": dtype}, name=name or "Placeholder", shape=tuple(shape) if shape else None)
+
+
+def Variable(initial_value, dtype=None, name=None, trainable=True) -> VariableNode:
+    return VariableNode(initial_value, dtype=dtype, name=name, trainable=trainable)
+
+
+def global_variables_initializer() -> Operation:
+    return Operation("init", [], name="init")
+
+
+# elementwise / reductions: symbolic constructors
+def round(x, name=None): return Tensor("round", [x], name=name)            # noqa: A001  (half-to-even like tf.round)
+def equal(x, y, name=None): return Tensor("equal", [x, y], name=name)
+def cast(x, dtype, name=None): return Tensor("cast", [x], {"dtype": _DTYPES.get(dtype, dtype)}, name=name)
+def square(x, name=None): return Tensor("square", [x], name=name)
+def subtract(x, y, name=None): return Tensor("sub", [x, y], name=name)
+def argmax(x, axis=None, name=None): return Tensor("argmax", [x], {"axis": axis}, name=name)
+def reduce_mean(x, axis=None, name=None): return Tensor("reduce_mean", [x], {"axis": axis}, name=name)
+def reduce_sum(x, axis=None, name=None): return Tensor("reduce_sum", [x], {"axis": axis}, name=name)
+def sigmoid(x, name=None): return Tensor("sigmoid", [x], name=name)
+
+
+def _eval_generic(node, env: Dict[Tensor, torch.Tensor], engine: "GraphEngine", training: bool):
+    """Eager evaluation of a node from fed placeholders (metric / debugging path, not the training path)."""
+    if not isinstance(node, Tensor):
+        return node
+    if node in env:
+        return env[node]
+    op = node.op
+    ins = [_eval_generic(i, env, engine, training) for i in node.inputs]
+    if op == "Placeholder":
+        raise ValueError("placeholder %s must be fed" % node.name)
+    if op == "layer":
+        out = node.attrs["layer"].forward(ins[0], training)
+        head = node.attrs["layer"]
+        if isinstance(head, _layers.Dense) and head.softmax and head.emit_logits:
+            from .ops import functional as F
+            out = F.softmax(out)
+    elif op == "round": out = torch.round(ins[0])
+    elif op == "equal": out = ins[0] == ins[1]
+    elif op == "cast": out = ins[0].to(node.attrs["dtype"])
+    elif op == "square": out = ins[0] * ins[0]
+    elif op == "sub": out = ins[0] - ins[1]
+    elif op == "add": out = ins[0] + ins[1]
+    elif op == "mul": out = ins[0] * ins[1]
+    elif op == "div": out = ins[0] / ins[1]
+    elif op == "sigmoid": out = torch.sigmoid(ins[0])
+    elif op == "argmax": out = ins[0].argmax(dim=node.attrs["axis"] if node.attrs["axis"] is not None else 0)
+    elif op == "reduce_mean":
+        out = ins[0].float().mean() if node.attrs["axis"] is None else ins[0].float().mean(dim=node.attrs["axis"])
+    elif op == "reduce_sum":
+        out = ins[0].sum() if node.attrs["axis"] is None else ins[0].sum(dim=node.attrs["axis"])
+    elif op == "keras_mse": out = ((ins[1] - ins[0]) ** 2).mean(dim=-1)
+    elif op == "softmax_xent":
+        out = -(ins[0] * torch.log_softmax(ins[1], dim=1)).sum(dim=1)
+    elif op == "sparse_softmax_xent":
+        out = torch.nn.functional.cross_entropy(ins[1], ins[0].long(), reduction="none")
+    elif op == "Variable":
+        out = engine.variable_value(node)
+    else:
+        raise NotImplementedError("cannot evaluate op %r" % op)
+    env[node] = out
+    return out
+
+
+# --------------------------------------------------------------------------- lowering onto the engine
+def _match(node, op):
+    return isinstance(node, Tensor) and node.op == op
+
+
+class GraphEngine(ModelEngine):
+    """Lowers the default graph onto a compiled ``Sequential`` and serves ``Session.run``."""
+
+    def __init__(self, graph: Graph):
+        self.graph = graph
+        self.train_op = next((n for n in graph.nodes if n.op == "minimize"), None)
+        self.loss_node = self.train_op.inputs[0] if self.train_op is not None else None
+        self.preds = self.labels = self.input = None
+        self.accuracy_nodes: List[Tensor] = []
+        self.model: Optional[_Sequential] = None
+        self._last_logs = {}
+        self.x_key, self.y_key, self.training_key = "x", "y", "training"
+        self.global_step_node = self.train_op.attrs.get("global_step") if self.train_op is not None else None
+        self._lower()
+
+    def _lower(self):
+        if self.train_op is None:
+            raise ValueError("the graph has no training op (optimizer.minimize(loss) was never called)")
+        loss_name, labels, preds = self._match_loss(self.loss_node)
+        self.labels, self.preds = labels, preds
+        chain = []
+        node = preds
+        while _match(node, "layer"):
+            chain.append(node.attrs["layer"])
+            node = node.inputs[0]
+        if not _match(node, "Placeholder"):
+            raise NotImplementedError("the model must be a chain of layers applied to a placeholder")
+        self.input = node
+        chain.reverse()
+        if node.shape is None or len(node.shape) < 2:
+            raise ValueError("input placeholder needs a (None, features...) shape")
+        model = _Sequential(chain, name="graph_model")
+        opt_node = self.train_op.attrs["optimizer"]
+        strategy = self._pick_strategy(opt_node)
+        metrics = []
+        for n in self.graph.nodes:
+            kind = self._match_accuracy(n)
+            if kind:
+                self.accuracy_nodes.append(n)
+                metrics = ["binary_rounded_accuracy"] if kind == "rounded" else ["accuracy"]
+        self._chain_input_shape = tuple(int(s) for s in node.shape[1:])
+        model.layers[0].input_shape = self._chain_input_shape
+        model.compile(loss=loss_name, optimizer=opt_node.optimizer, metrics=metrics or ["accuracy"],
+                      strategy=strategy, device=_pick_device(), seed=self.graph.__dict__.get("seed"))
+        self.model = model
+        self.graph.finalize()
+
+    def _pick_strategy(self, opt_node):
+        srv = _cluster.current_server()
+        setter = self.graph.device_setter
+        if isinstance(opt_node, SyncReplicasOptimizer):
+            from .parallel import Communicator, SyncReplicasStrategy, init_process_group
+            import torch.distributed as dist
+            if not dist.is_initialized():
+                if srv is None:
+                    return None
+                host, port = srv.rendezvous_address()
+                init_process_group(None, rank=srv.task_index, world_size=srv.num_workers, master_addr=host,
+                                   master_port=port)
+            return SyncReplicasStrategy(Communicator())
+        if srv is not None and setter is not None and setter.cluster is not None:
+            from .parallel.async_ps import AsyncPSStrategy
+            return AsyncPSStrategy(srv, max_staleness=self.graph.__dict__.get("max_staleness"),
+                                   placement=setter.strategy.name)
+        return None
+
+    def _match_loss(self, node):
+        if _match(node, "reduce_mean") and _match(node.inputs[0], "keras_mse"):
+            m = node.inputs[0]
+            return "mean_squared_error", m.inputs[0], m.inputs[1]
+        if _match(node, "reduce_mean") and _match(node.inputs[0], "softmax_xent"):
+            m = node.inputs[0]
+            return "categorical_crossentropy", m.inputs[0], m.inputs[1]
+        if _match(node, "reduce_mean") and _match(node.inputs[0], "sparse_softmax_xent"):
+            m = node.inputs[0]
+            return "sparse_categorical_crossentropy", m.inputs[0], m.inputs[1]
+        if _match(node, "reduce_mean") and _match(node.inputs[0], "square") and _match(node.inputs[0].inputs[0], "sub"):
+            s = node.inputs[0].inputs[0]
+            a, b = s.inputs
+            preds, labels = (a, b) if _match(a, "layer") else (b, a)
+            return "mean_squared_error", labels, preds
+        raise NotImplementedError(
+            "minimize() supports reduce_mean of keras.losses.mean_squared_error, tf.square(a - b), "
+            "tf.nn.softmax_cross_entropy_with_logits or tf.nn.sparse_softmax_cross_entropy_with_logits")
+
+    def _match_accuracy(self, node) -> Optional[str]:
+        """mean(cast(equal(round(p), round(y)))) -> 'rounded'; mean(cast(equal(argmax(p), argmax(y)))) -> 'argmax'."""
+        if not (_match(node, "reduce_mean") and _match(node.inputs[0], "cast") and _match(node.inputs[0].inputs[0], "equal")):
+            return None
+        a, b = node.inputs[0].inputs[0].inputs
+        if _match(a, "round") and _match(b, "round"):
+            ends = {a.inputs[0], b.inputs[0]}
+            return "rounded" if ends == {self.preds, self.labels} else None
+        if _match(a, "argmax") and _match(b, "argmax"):
+            ends = {a.inputs[0], b.inputs[0]}
+            return "argmax" if ends == {self.preds, self.labels} else None
+        return None
+
+    # ---- engine protocol
+    def ensure_built(self):
+        pass
+
+    def describe(self) -> str:
+        import json
+        return json.dumps(self.graph.as_graph_def(), indent=1)
+
+    def variable_value(self, node):
+        if node is self.global_step_node or node.name.endswith("global_step"):
+            return self.global_step_value()
+        raise KeyError("variable %s has no value in this graph" % node.name)
+
+    def resolve(self, fetch):
+        if fetch is self.train_op:
+            return TRAIN_OP
+        if fetch is self.loss_node:
+            return LOSS
+        if fetch in self.accuracy_nodes:
+            return ACCURACY
+        if fetch is self.global_step_node:
+            return GLOBAL_STEP
+        if isinstance(fetch, Operation) and fetch.op == "init":
+            return lambda: None
+        if isinstance(fetch, Tensor):
+            return lambda f=fetch: self._eval_node(f)
+        return fetch
+
+    def _eval_node(self, node):
+        env = dict(self._env)
+        out = _eval_generic(node, env, self, self._training)
+        if isinstance(out, torch.Tensor):
+            return out.item() if out.dim() == 0 else out.detach().cpu().numpy()
+        return out
+
+    def run(self, fetch_struct, feed_dict=None):
+        feed = {}
+        self._env = {}
+        self._training = False
+        for k, v in (feed_dict or {}).items():
+            if k is self.input:
+                feed["x"] = v
+            elif k is self.labels:
+                feed["y"] = v
+            elif k is self.graph.learning_phase:
+                feed["training"] = bool(v)
+                self._training = bool(v)
+            elif isinstance(k, Tensor):
+                self._env[k] = _as_tensor(v, self.model.device)
+            else:
+                feed[k] = v
+        if "x" in feed:
+            self._env[self.input] = _as_tensor(feed["x"], self.model.device)
+        if "y" in feed:
+            self._env[self.labels] = _as_tensor(feed["y"], self.model.device)
+        return super().run(fetch_struct, feed)
+
+
+def _pick_device():
+    srv = _cluster.current_server()
+    if srv is not None:
+        return srv.device()
+    return None
+
+
+# --------------------------------------------------------------------------- sessions
+class _SessionWrapper:
+    """Adds the ``with sess:`` default-session behaviour on top of MonitoredSession."""
+
+    def __init__(self, inner):
+        self._inner = inner
+
+    def __enter__(self):
+        self._inner.__enter__()
+        _session_stack.append(self)
+        return self
+
+    def __exit__(self, *exc):
+        if _session_stack and _session_stack[-1] is self:
+            _session_stack.pop()
+        return self._inner.__exit__(*exc)
+
+    def __getattr__(self, name):
+        return getattr(self._inner, name)
+
+
+def _monitored_training_session(*args, **kwargs):
+    kwargs.setdefault("engine", get_default_graph().engine())
+    return _SessionWrapper(_session.MonitoredTrainingSession(*args, **kwargs))
+
+
+def Session(target: str = "", graph: Optional[Graph] = None, config=None):
+    """Plain ``tf.Session``: a monitored session without hooks or checkpoints."""
+    g = graph or get_default_graph()
+    return _SessionWrapper(_session.MonitoredSession(g.engine(), is_chief=True, master=target))
+
+
+# --------------------------------------------------------------------------- optimizers (graph style)
+class _GraphOptimizer:
+    def __init__(self, optimizer: _optimizers.Optimizer):
+        self.optimizer = optimizer
+
+    def minimize(self, loss: Tensor, global_step: Optional[Tensor] = None, name=None) -> Operation:
+        return Operation("minimize", [loss], {"optimizer": self, "global_step": global_step}, name=name or "minimize")
+
+
+class AdamOptimizer(_GraphOptimizer):
+    def __init__(self, learning_rate=0.001, beta1=0.9, beta2=0.999, epsilon=1e-8, use_locking=False, name="Adam"):
+        super().__init__(_optimizers.Adam(lr=learning_rate, beta_1=beta1, beta_2=beta2, epsilon=epsilon))
+
+
+class GradientDescentOptimizer(_GraphOptimizer):
+    def __init__(self, learning_rate, use_locking=False, name="GradientDescent"):
+        super().__init__(_optimizers.SGD(lr=learning_rate))
+
+
+class MomentumOptimizer(_GraphOptimizer):
+    def __init__(self, learning_rate, momentum, use_locking=False, name="Momentum"):
+        super().__init__(_optimizers.SGD(lr=learning_rate, momentum=momentum))
+
+
+class SyncReplicasOptimizer(_GraphOptimizer):
+    """``tf.train.SyncReplicasOptimizer(opt, replicas_to_aggregate=N)``: gradients of all workers are averaged
+    and applied once per global step (reduce-scatter / sharded apply / all-gather)."""
+
+    def __init__(self, opt: _GraphOptimizer, replicas_to_aggregate: Optional[int] = None,
+                 total_num_replicas: Optional[int] = None, name="sync_replicas"):
+        super().__init__(opt.optimizer)
+        self.replicas_to_aggregate = replicas_to_aggregate
+
+    def make_session_run_hook(self, is_chief, num_tokens=-1):
+        return _session.SessionRunHook()
+
+
+# --------------------------------------------------------------------------- namespaces mirroring tf.*
+def _softmax_xent(labels=None, logits=None, name=None, **_):
+    return Tensor("softmax_xent", [labels, logits], name=name)
+
+
+def _sparse_softmax_xent(labels=None, logits=None, name=None, **_):
+    return Tensor("sparse_softmax_xent", [labels, logits], name=name)
+
+
+nn = types.SimpleNamespace(softmax_cross_entropy_with_logits=_softmax_xent,
+                           softmax_cross_entropy_with_logits_v2=_softmax_xent,
+                           sparse_softmax_cross_entropy_with_logits=_sparse_softmax_xent,
+                           sigmoid=sigmoid)
+
+summary = types.SimpleNamespace(scalar=_summary.scalar, merge_all=_summary.merge_all, merge=_summary.merge,
+                                FileWriter=_summary.FileWriter, Summary=_summary.Summary)
+
+train = types.SimpleNamespace(
+    AdamOptimizer=AdamOptimizer, GradientDescentOptimizer=GradientDescentOptimizer, MomentumOptimizer=MomentumOptimizer,
+    SyncReplicasOptimizer=SyncReplicasOptimizer, ClusterSpec=_cluster.ClusterSpec, Server=_cluster.Server,
+    replica_device_setter=_cluster.replica_device_setter, StopAtStepHook=_session.StopAtStepHook,
+    StepCounterHook=_session.StepCounterHook, SummarySaverHook=_session.SummarySaverHook,
+    CheckpointSaverHook=_session.CheckpointSaverHook, LoggingTensorHook=_session.LoggingTensorHook,
+    SessionRunHook=_session.SessionRunHook, SessionRunArgs=_session.SessionRunArgs, Scaffold=_session.Scaffold,
+    MonitoredTrainingSession=_monitored_training_session, Saver=_saver.Saver,
+    latest_checkpoint=_saver.latest_checkpoint, load_checkpoint=_saver.load_checkpoint,
+    list_variables=_saver.list_variables)
+
+app = types.SimpleNamespace(flags=_flags)
+flags = _flags
+
+
+# --------------------------------------------------------------------------- keras namespace
+class _SymbolicLayerMixin:
+    """Makes a layer callable on symbolic tensors: ``Dense(128, activation='relu')(input_)``."""
+
+    def __call__(self, x):
+        if isinstance(x, Tensor):
+            return Tensor("layer", [x], {"layer": self}, name=type(self).__name__.lower())
+        return self.forward(x, training=False)
+
+
+class _Dense(_SymbolicLayerMixin, _layers.Dense):
+    pass
+
+
+class _Dropout(_SymbolicLayerMixin, _layers.Dropout):
+    pass
+
+
+class _Activation(_SymbolicLayerMixin, _layers.Activation):
+    pass
+
+
+class _Flatten(_SymbolicLayerMixin, _layers.Flatten):
+    pass
+
+
+class _KerasBackend:
+    _session = None
+
+    @staticmethod
+    def learning_phase() -> Tensor:
+        g = get_default_graph()
+        if g.learning_phase is None:
+            g.learning_phase = Tensor("Placeholder", [], {"dtype": torch.bool}, name="keras_learning_phase", shape=())
+        return g.learning_phase
+
+    @staticmethod
+    def set_session(sess):
+        _KerasBackend._session = sess
+
+    @staticmethod
+    def get_session():
+        return _KerasBackend._session
+
+
+def _keras_mse(y_true, y_pred):
+    if isinstance(y_true, Tensor) or isinstance(y_pred, Tensor):
+        return Tensor("keras_mse", [y_true, y_pred], name="mean_squared_error")
+    return _losses.mean_squared_error(y_true, y_pred)
+
+
+keras = types.SimpleNamespace(
+    layers=types.SimpleNamespace(Dense=_Dense, Dropout=_Dropout, Activation=_Activation, Flatten=_Flatten),
+    models=types.SimpleNamespace(Sequential=_Sequential),
+    backend=_KerasBackend,
+    losses=types.SimpleNamespace(mean_squared_error=_keras_mse),
+    callbacks=types.SimpleNamespace(TensorBoard=_callbacks.TensorBoard, Callback=_callbacks.Callback,
+                                    History=_callbacks.History),
+    optimizers=types.SimpleNamespace(Adam=_optimizers.Adam, SGD=_optimizers.SGD),
+)

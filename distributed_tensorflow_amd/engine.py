@@ -1,0 +1,199 @@
+"""Train-engine adapter: what :class:`~distributed_tensorflow_amd.session.MonitoredSession` drives.
+
+It wraps a compiled :class:`~distributed_tensorflow_amd.models.Sequential` (variables,
+optimizer, parallel strategy) and resolves *fetches*:
+
+* ``"train_op"``            - one optimisation step on the fed batch;
+* ``"loss"`` / ``"accuracy"`` - mean over the batch of this run (one device->host read);
+* ``"global_step"``         - the (cluster-wide) step counter;
+* a summary op (``summary.scalar`` / ``merge_all``) - evaluated into a ``Summary``;
+* any callable              - called with no arguments.
+
+The graph-style front end (:mod:`distributed_tensorflow_amd.compat`) subclasses this and maps its
+symbolic nodes onto the same fetch names.
+"""
+from __future__ import annotations
+
+import json
+import uuid
+from typing import Any, Dict, List, Optional
+
+import torch
+
+from . import saver as saver_mod
+from . import summary as summary_mod
+
+TRAIN_OP, LOSS, ACCURACY, GLOBAL_STEP = "train_op", "loss", "accuracy", "global_step"
+
+
+class ModelEngine:
+    def __init__(self, model, x_key="x", y_key="y", training_key="training"):
+        self.model = model
+        self.x_key, self.y_key, self.training_key = x_key, y_key, training_key
+        self._last_logs: Dict[str, float] = {}
+
+    # ---- structure
+    @property
+    def store(self):
+        return self.model.store
+
+    @property
+    def optimizer(self):
+        return self.model.optimizer
+
+    @property
+    def strategy(self):
+        return self.model.strategy
+
+    def ensure_built(self):
+        if not self.model.compiled:
+            raise RuntimeError("compile() the model before opening a session")
+
+    def describe(self) -> str:
+        return json.dumps(self.model.get_config(), indent=1, default=str)
+
+    # ---- global step
+    def global_step_value(self) -> int:
+        gs = getattr(self.model.strategy, "global_step", None)
+        if callable(gs):
+            return int(gs())
+        return int(self.model.store.global_step.item())
+
+    # ---- checkpoints
+    def make_saver(self, max_to_keep: int = 5):
+        st = self.model.strategy
+        placement = getattr(st, "placement", None) or {}
+        shards = getattr(st, "num_owners", 1) if placement and not all(v == -1 for v in placement.values()) else 1
+        return saver_mod.Saver(self.model.store, self.model.optimizer, max_to_keep=max_to_keep,
+                               placement=placement if shards > 1 else None, num_shards=shards)
+
+    def save_checkpoint(self, saver, save_path: str, step: int) -> str:
+        st = self.model.strategy
+        prefix = "%s-%d" % (save_path, int(step))
+        if hasattr(st, "save") and getattr(st, "placement_name", "") != "flat":
+            # asynchronous parameter servers: every owner writes its own shard, the chief merges
+            st.save(self.model, prefix, uuid.uuid4().hex)
+            saver._record(prefix)
+            return prefix
+        if hasattr(st, "gather_slots"):
+            st.gather_slots(self.model)          # collective: every replica takes part
+            if st.rank != 0:
+                return prefix
+        if hasattr(st, "pull"):
+            st.pull(self.model)                  # flat-sharded owners: fetch current values first
+        return saver.save(save_path, global_step=step)
+
+    def restore_checkpoint(self, saver, prefix: str) -> int:
+        step = saver.restore(prefix)
+        self.model._host_step = step
+        return step
+
+    def synchronize_state(self, is_chief: bool):
+        st = self.model.strategy
+        if hasattr(st, "broadcast_state"):
+            st.broadcast_state(self.model)
+        elif hasattr(st, "publish_state"):
+            st.publish_state(self.model, is_chief)
+
+    # ---- running
+    def _feed(self, feed_dict, key, default=None):
+        if feed_dict is None:
+            return default
+        return feed_dict.get(key, default)
+
+    def _to_device(self, a, labels=False):
+        from .models.sequential import _as_tensor
+        return _as_tensor(a, self.model.device)
+
+    def resolve(self, fetch):
+        """Map a caller-level fetch object to an engine fetch name / callable (overridden by the graph engine)."""
+        return fetch
+
+    def run(self, fetch_struct: Dict[str, Any], feed_dict: Optional[Dict] = None) -> Dict[str, Any]:
+        flat: List[Any] = []
+
+        def walk(f):
+            if isinstance(f, (list, tuple)):
+                for g in f:
+                    walk(g)
+            elif isinstance(f, dict):
+                for g in f.values():
+                    walk(g)
+            elif f is not None:
+                flat.append(self.resolve(f))
+
+        walk(fetch_struct)
+        names = [f for f in flat if isinstance(f, str)]
+        x = self._feed(feed_dict, self.x_key)
+        y = self._feed(feed_dict, self.y_key)
+        training = bool(self._feed(feed_dict, self.training_key, TRAIN_OP in names))
+        need_stats = LOSS in names or ACCURACY in names or any(
+            isinstance(f, (summary_mod.MergedSummaryOp, summary_mod.ScalarSummaryOp)) for f in flat)
+        m = self.model
+        if TRAIN_OP in names:
+            if x is None or y is None:
+                raise ValueError("train_op needs both inputs and labels in feed_dict")
+            xd, yd = self._to_device(x), self._to_device(y)
+            if need_stats:
+                m.stats.zero_()
+            if training:
+                m.train_step(xd, yd)
+            else:
+                # learning phase 0 with a training op: update without dropout
+                out = m.forward(xd, training=False)
+                g = m._loss_and_metrics(out, yd, True, m.stats)
+                m.backward(g)
+                m.strategy.apply_gradients(m)
+                m._host_step += 1
+            if need_stats:
+                self._last_logs = m.read_stats()
+        elif need_stats:
+            if x is None or y is None:
+                raise ValueError("evaluating loss/accuracy needs inputs and labels in feed_dict")
+            xd, yd = self._to_device(x), self._to_device(y)
+            from .ops import functional as F
+            st = F.new_stats(m.device)
+            out = m.forward(xd, training=training)
+            m._loss_and_metrics(out, yd, False, st)
+            self._last_logs = m.read_stats(stats=st)
+
+        def value(f):
+            f = self.resolve(f)
+            if isinstance(f, str):
+                if f == TRAIN_OP:
+                    return None
+                if f == LOSS:
+                    return self._last_logs["loss"]
+                if f == ACCURACY:
+                    return self._last_logs.get("binary_rounded_accuracy", self._last_logs.get("acc"))
+                if f == GLOBAL_STEP:
+                    return self.global_step_value()
+                if f == "predictions":
+                    return m.predict(x, batch_size=len(x))
+                raise KeyError("unknown fetch %r" % f)
+            if isinstance(f, summary_mod.ScalarSummaryOp):
+                v = value(f.source)
+                if hasattr(v, "item"):
+                    v = v.item()
+                return summary_mod.Summary([(f.name, float(v))])
+            if isinstance(f, summary_mod.MergedSummaryOp):
+                merged = summary_mod.Summary()
+                for op in f.ops:
+                    merged.value.extend(value(op).value)
+                return merged
+            if callable(f):
+                return f()
+            return f
+
+        def rebuild(f):
+            if isinstance(f, list):
+                return [rebuild(g) for g in f]
+            if isinstance(f, tuple):
+                return tuple(rebuild(g) for g in f)
+            if isinstance(f, dict):
+                return {k: rebuild(g) for k, g in f.items()}
+            if f is None:
+                return None
+            return value(f)
+
+        return rebuild(fetch_struct)

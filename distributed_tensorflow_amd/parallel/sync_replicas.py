@@ -172,6 +172,37 @@ class SyncReplicasStrategy:
         self.comm.all_reduce_sum(s)
         return s
 
+    def broadcast_state(self, model):
+        """Chief-initialises / others-wait: the chief's variables, slots and step win on every replica."""
+        store = model.store
+        self.comm.broadcast(store.flat, 0)
+        self.comm.broadcast(store.global_step, 0)
+        self.comm.broadcast(store.beta_powers, 0)
+        for name in sorted(store.slots):
+            self.comm.broadcast(store.slots[name], 0)
+
+    def gather_slots(self, model):
+        """Collective: make every replica's optimizer-slot buffers complete (each replica only updates the
+        slots of the shards it owns), so that the chief can write a full checkpoint."""
+        if self.world_size == 1:
+            return
+        store = model.store
+        for name in sorted(store.slots):
+            s = store.slots[name]
+            for b in self.buckets:
+                self.comm.all_gather(s[b.begin:b.end], s[b.shard_begin:b.shard_end])
+
+    def agree(self, flag: bool) -> bool:
+        """The chief's boolean decision, on every replica (one tiny broadcast)."""
+        if self.world_size == 1:
+            return bool(flag)
+        t = torch.tensor([1 if flag else 0], dtype=torch.int64, device=self.buckets[0].shard.device if self.buckets
+                         else "cpu")
+        self.comm.broadcast(t, 0)
+        return bool(t.item())
+
+    collective_checkpoint = True
+
 
 class _ShardView:
     """Presents one bucket shard of a VariableStore as a tiny store so ``Optimizer.apply`` runs on it unchanged."""

@@ -1,0 +1,410 @@
+"""``MonitoredTrainingSession`` and the session-run hook protocol.
+
+What one call gives the reference (/root/reference/example.py:187-192): the chief
+initialises or restores the variables and everybody else waits for it; a checkpoint is
+written at the first step, every ``save_checkpoint_secs`` (600) and at the end; summaries
+every ``save_summaries_steps`` (100); ``global_step/sec`` every 100 steps; hooks run around
+every ``run`` call; ``should_stop()`` turns true when a hook asks for it
+(``StopAtStepHook(last_step=...)`` counts *absolute* global steps, so a restarted job
+continues instead of starting over); recoverable errors make the session re-create itself
+from the last checkpoint and retry.
+
+The session drives a *train engine*: any object with ``store`` (VariableStore),
+``optimizer``, ``strategy``, ``run(fetches, feed_dict)`` and ``global_step_value()`` - the
+graph-style front end in :mod:`distributed_tensorflow_amd.compat` and
+:class:`~distributed_tensorflow_amd.models.Sequential` both provide it.
+"""
+from __future__ import annotations
+
+import os
+import time
+import uuid
+from typing import Any, Dict, List, Optional, Sequence
+
+from . import saver as saver_mod
+from . import summary as summary_mod
+
+
+# --------------------------------------------------------------------------- errors
+class AbortedError(RuntimeError):
+    """A peer task or the transport went away mid-step; the session may recover from a checkpoint."""
+
+
+class UnavailableError(RuntimeError):
+    """A peer task cannot be reached (yet); recoverable."""
+
+
+class OutOfRangeError(RuntimeError):
+    """Input exhausted: ends the monitored loop cleanly."""
+
+
+RECOVERABLE_ERRORS = (AbortedError, UnavailableError)
+
+
+# --------------------------------------------------------------------------- hook protocol
+class SessionRunArgs:
+    def __init__(self, fetches=None, feed_dict=None):
+        self.fetches = fetches
+        self.feed_dict = feed_dict
+
+
+class SessionRunValues:
+    def __init__(self, results=None):
+        self.results = results
+
+
+class SessionRunContext:
+    def __init__(self, original_args: SessionRunArgs, session: "MonitoredSession"):
+        self.original_args = original_args
+        self.session = session
+        self._stop_requested = False
+
+    @property
+    def stop_requested(self) -> bool:
+        return self._stop_requested
+
+    def request_stop(self):
+        self._stop_requested = True
+
+
+class SessionRunHook:
+    def begin(self): pass
+    def after_create_session(self, session, coord): pass
+    def before_run(self, run_context: SessionRunContext) -> Optional[SessionRunArgs]: return None
+    def after_run(self, run_context: SessionRunContext, run_values: SessionRunValues): pass
+    def end(self, session): pass
+
+
+class StopAtStepHook(SessionRunHook):
+    """Request a stop once ``global_step >= last_step`` (or after ``num_steps`` more steps)."""
+
+    def __init__(self, num_steps: Optional[int] = None, last_step: Optional[float] = None):
+        if (num_steps is None) == (last_step is None):
+            raise ValueError("exactly one of num_steps and last_step must be given")
+        self._num_steps, self._last_step = num_steps, last_step
+
+    def after_create_session(self, session, coord):
+        if self._last_step is None:
+            self._last_step = session.global_step_value() + self._num_steps
+        if session.global_step_value() >= self._last_step:
+            session.request_stop()
+
+    def after_run(self, run_context, run_values):
+        if run_context.session.global_step_value() >= self._last_step:
+            run_context.request_stop()
+
+
+class StepCounterHook(SessionRunHook):
+    """``global_step/sec`` (and examples/sec when the batch size is known) every N steps."""
+
+    def __init__(self, every_n_steps: int = 100, summary_writer=None, output_dir: Optional[str] = None,
+                 batch_size: Optional[int] = None, log=print):
+        self.every, self.writer, self.output_dir, self.batch_size, self.log = every_n_steps, summary_writer, output_dir, batch_size, log
+        self._last_step = None
+        self._last_time = None
+        self.last_rate = None
+
+    def after_create_session(self, session, coord):
+        if self.writer is None and self.output_dir:
+            self.writer = summary_mod.FileWriterCache.get(self.output_dir)
+        self._last_step, self._last_time = session.global_step_value(), time.time()
+
+    def after_run(self, run_context, run_values):
+        step = run_context.session.global_step_value()
+        if step - self._last_step >= self.every:
+            now = time.time()
+            rate = (step - self._last_step) / max(now - self._last_time, 1e-9)
+            self.last_rate = rate
+            if self.writer is not None:
+                vals = [("global_step/sec", rate)]
+                if self.batch_size:
+                    vals.append(("examples/sec", rate * self.batch_size))
+                self.writer.add_summary(summary_mod.Summary(vals), step)
+            if self.log:
+                self.log("INFO: global_step/sec: %g" % rate)
+            self._last_step, self._last_time = step, now
+
+    def end(self, session):
+        if self.writer is not None:
+            self.writer.flush()
+
+
+class SummarySaverHook(SessionRunHook):
+    """Evaluate ``summary_op`` (default: ``merge_all()``) every N steps and write it at the true global step."""
+
+    def __init__(self, save_steps: int = 100, output_dir: Optional[str] = None, summary_writer=None, summary_op=None):
+        self.save_steps, self.output_dir, self.writer, self.summary_op = save_steps, output_dir, summary_writer, summary_op
+        self._next = None
+        self._own_writer = False
+
+    def begin(self):
+        if self.summary_op is None:
+            self.summary_op = summary_mod.merge_all()
+
+    def after_create_session(self, session, coord):
+        if self.writer is None and self.output_dir:
+            self.writer = summary_mod.FileWriterCache.get(self.output_dir)
+        self._next = session.global_step_value()
+
+    def before_run(self, run_context):
+        self._want = self.summary_op is not None and run_context.session.global_step_value() >= self._next
+        return SessionRunArgs(fetches=self.summary_op) if self._want else None
+
+    def after_run(self, run_context, run_values):
+        if self._want and self.writer is not None and run_values.results is not None:
+            step = run_context.session.global_step_value()
+            self.writer.add_summary(run_values.results, step)
+            self._next = step + self.save_steps
+
+    def end(self, session):
+        if self.writer is not None:
+            self.writer.flush()
+
+
+class CheckpointSaverHook(SessionRunHook):
+    """Chief-only: save at the first step, every ``save_secs`` / ``save_steps``, and at ``end``."""
+
+    def __init__(self, checkpoint_dir: str, save_secs: Optional[float] = 600.0, save_steps: Optional[int] = None,
+                 saver=None, checkpoint_basename: str = "model.ckpt"):
+        self.dir, self.save_secs, self.save_steps, self.saver = checkpoint_dir, save_secs, save_steps, saver
+        self.basename = checkpoint_basename
+        self._last_time = None
+        self._last_step = None
+        self.saved_steps: List[int] = []
+
+    def after_create_session(self, session, coord):
+        os.makedirs(self.dir, exist_ok=True)
+        # TF writes graph.pbtxt here; we write a readable description of the model next to the checkpoints
+        try:
+            with open(os.path.join(self.dir, "graph.pbtxt"), "w") as f:
+                f.write("# model description (not a TensorFlow GraphDef)\n%s\n" % session.describe_graph())
+        except OSError:
+            pass
+
+    def _save(self, session, step: int):
+        session.save_checkpoint(os.path.join(self.dir, self.basename), step, saver=self.saver)
+        self._last_time, self._last_step = time.time(), step
+        self.saved_steps.append(step)
+
+    def after_run(self, run_context, run_values):
+        s = run_context.session
+        step = s.global_step_value()
+        if self._last_step is None:
+            if step > 0:
+                self._save(s, step)
+            return
+        due = (self.save_secs is not None and time.time() - self._last_time >= self.save_secs) or \
+              (self.save_steps is not None and step - self._last_step >= self.save_steps)
+        if due and step != self._last_step:
+            self._save(s, step)
+
+    def end(self, session):
+        step = session.global_step_value()
+        if step != self._last_step:
+            self._save(session, step)
+
+
+class LoggingTensorHook(SessionRunHook):
+    def __init__(self, tensors: Dict[str, Any], every_n_iter: int = 100, log=print):
+        self.tensors, self.every, self.log = tensors, every_n_iter, log
+        self._iter = 0
+
+    def before_run(self, run_context):
+        self._want = self._iter % self.every == 0
+        return SessionRunArgs(fetches=list(self.tensors.values())) if self._want else None
+
+    def after_run(self, run_context, run_values):
+        if self._want and run_values.results is not None:
+            self.log("INFO: " + ", ".join("%s = %s" % (k, v) for k, v in zip(self.tensors, run_values.results)))
+        self._iter += 1
+
+
+class NanLossHook(SessionRunHook):
+    """Stop (or raise) when the watched loss becomes NaN."""
+
+    def __init__(self, loss_tensor, fail_on_nan_loss: bool = True):
+        self.loss, self.fail = loss_tensor, fail_on_nan_loss
+
+    def before_run(self, run_context):
+        return SessionRunArgs(fetches=self.loss)
+
+    def after_run(self, run_context, run_values):
+        v = run_values.results
+        if v is not None and v != v:
+            if self.fail:
+                raise FloatingPointError("NaN loss during training")
+            run_context.request_stop()
+
+
+class FaultInjectionHook(SessionRunHook):
+    """Test hook: raise a recoverable (or fatal) error when ``global_step`` reaches ``at_step``, once."""
+
+    def __init__(self, at_step: int, error: type = AbortedError, kill_process: bool = False):
+        self.at_step, self.error, self.kill = at_step, error, kill_process
+        self.fired = False
+
+    def before_run(self, run_context):
+        if not self.fired and run_context.session.global_step_value() >= self.at_step:
+            self.fired = True
+            if self.kill:
+                os._exit(17)
+            raise self.error("injected fault at global_step %d" % self.at_step)
+        return None
+
+
+# --------------------------------------------------------------------------- scaffold
+class Scaffold:
+    """Holds the pieces a session needs once the model is final (saver, summary op, init callbacks)."""
+
+    def __init__(self, saver=None, summary_op=None, init_fn=None):
+        self.saver = saver
+        self.summary_op = summary_op
+        self.init_fn = init_fn
+
+
+# --------------------------------------------------------------------------- sessions
+class MonitoredSession:
+    def __init__(self, engine, is_chief: bool = True, master: str = "", checkpoint_dir: Optional[str] = None,
+                 hooks: Optional[Sequence[SessionRunHook]] = None, scaffold: Optional[Scaffold] = None,
+                 max_recoveries: int = 8, recovery_wait_secs: float = 1.0, stop_grace_period_secs: float = 120.0):
+        self.engine = engine
+        self.is_chief = is_chief
+        self.master = master
+        self.checkpoint_dir = checkpoint_dir
+        self.hooks: List[SessionRunHook] = list(hooks or [])
+        self.scaffold = scaffold or Scaffold()
+        self.max_recoveries = max_recoveries
+        self.recovery_wait_secs = recovery_wait_secs
+        self._stop = False
+        self._closed = False
+        self._recoveries = 0
+        self.graph = getattr(engine, "graph", engine)
+
+    # -- engine pass-throughs
+    def global_step_value(self) -> int:
+        return int(self.engine.global_step_value())
+
+    def describe_graph(self) -> str:
+        d = getattr(self.engine, "describe", None)
+        return d() if d else repr(self.engine)
+
+    def _saver(self, saver=None):
+        if saver is not None:
+            return saver
+        if self.scaffold.saver is None:
+            self.scaffold.saver = self.engine.make_saver()
+        return self.scaffold.saver
+
+    def save_checkpoint(self, save_path: str, step: int, saver=None) -> str:
+        return self.engine.save_checkpoint(self._saver(saver), save_path, step)
+
+    # -- lifecycle
+    def _create(self, first: bool):
+        """Chief: restore from the latest checkpoint or initialise; then publish the state to the other tasks."""
+        self.engine.ensure_built()
+        restored = False
+        if self.is_chief and self.checkpoint_dir:
+            latest = saver_mod.latest_checkpoint(self.checkpoint_dir)
+            if latest:
+                self.engine.restore_checkpoint(self._saver(), latest)
+                restored = True
+        if self.is_chief and not restored and self.scaffold.init_fn is not None and first:
+            self.scaffold.init_fn(self)
+        self.engine.synchronize_state(self.is_chief)   # chief's values win everywhere; non-chiefs wait here
+        return restored
+
+    def __enter__(self):
+        for h in self.hooks:
+            h.begin()
+        self._create(first=True)
+        for h in self.hooks:
+            h.after_create_session(self, None)
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        if exc_type is not None and issubclass(exc_type, (OutOfRangeError, StopIteration)):
+            self.close()
+            return True
+        self.close(run_end_hooks=exc_type is None)
+        return False
+
+    def should_stop(self) -> bool:
+        return self._stop or self._closed
+
+    def request_stop(self):
+        self._stop = True
+
+    def run(self, fetches, feed_dict=None):
+        """Run ``fetches`` with the hooks' extra fetches; recoverable errors trigger restore-and-retry."""
+        if self._closed:
+            raise RuntimeError("session is closed")
+        while True:
+            try:
+                return self._run_once(fetches, feed_dict)
+            except RECOVERABLE_ERRORS as e:
+                self._recoveries += 1
+                if self._recoveries > self.max_recoveries:
+                    raise
+                print("INFO: recoverable error (%s); re-creating the session from the last checkpoint" % e)
+                time.sleep(self.recovery_wait_secs)
+                self._create(first=False)
+
+    def _run_once(self, fetches, feed_dict):
+        ctx = SessionRunContext(SessionRunArgs(fetches, feed_dict), self)
+        extra = []
+        for h in self.hooks:
+            req = h.before_run(ctx)
+            extra.append(req.fetches if req is not None else None)
+            if req is not None and req.feed_dict:
+                feed_dict = dict(feed_dict or {}, **req.feed_dict)
+        hook_fetches = [f for f in extra if f is not None]
+        results = self.engine.run({"caller": fetches, "hooks": hook_fetches}, feed_dict)
+        hook_results = iter(results["hooks"])
+        for h, f in zip(self.hooks, extra):
+            h.after_run(ctx, SessionRunValues(next(hook_results) if f is not None else None))
+        if ctx.stop_requested:
+            self._stop = True
+        return results["caller"]
+
+    def close(self, run_end_hooks: bool = True):
+        if self._closed:
+            return
+        if run_end_hooks:
+            for h in self.hooks:
+                h.end(self)
+        self._closed = True
+
+
+def MonitoredTrainingSession(master: str = "", is_chief: bool = True, checkpoint_dir: Optional[str] = None,
+                             scaffold: Optional[Scaffold] = None, hooks: Optional[Sequence[SessionRunHook]] = None,
+                             chief_only_hooks: Optional[Sequence[SessionRunHook]] = None,
+                             save_checkpoint_secs: Optional[float] = 600.0, save_summaries_steps: Optional[int] = 100,
+                             save_summaries_secs: Optional[float] = None, config=None,
+                             stop_grace_period_secs: float = 120.0, log_step_count_steps: Optional[int] = 100,
+                             engine=None, max_recoveries: int = 8) -> MonitoredSession:
+    """``tf.train.MonitoredTrainingSession`` (/root/reference/example.py:189-192).
+
+    ``engine`` defaults to the default graph of :mod:`distributed_tensorflow_amd.compat`.  When
+    ``checkpoint_dir`` is given the chief gets the TF default hooks: step counter (every
+    ``log_step_count_steps``), summary saver (every ``save_summaries_steps``) and checkpoint saver
+    (every ``save_checkpoint_secs``, plus first step and end).
+    """
+    if engine is None:
+        from . import compat
+        engine = compat.get_default_graph().engine()
+    all_hooks: List[SessionRunHook] = []
+    if is_chief and chief_only_hooks:
+        all_hooks.extend(chief_only_hooks)
+    if is_chief and checkpoint_dir:
+        if log_step_count_steps:
+            all_hooks.append(StepCounterHook(every_n_steps=log_step_count_steps, output_dir=checkpoint_dir, log=None))
+        if save_summaries_steps:
+            all_hooks.append(SummarySaverHook(save_steps=save_summaries_steps, output_dir=checkpoint_dir,
+                                              summary_op=scaffold.summary_op if scaffold else None))
+        if save_checkpoint_secs:
+            all_hooks.append(CheckpointSaverHook(checkpoint_dir, save_secs=save_checkpoint_secs,
+                                                 saver=scaffold.saver if scaffold else None))
+    all_hooks.extend(hooks or [])
+    return MonitoredSession(engine, is_chief=is_chief, master=master, checkpoint_dir=checkpoint_dir, hooks=all_hooks,
+                            scaffold=scaffold, max_recoveries=max_recoveries,
+                            stop_grace_period_secs=stop_grace_period_secs)
