@@ -293,11 +293,25 @@ class Server:
         self._ps_service = ParameterServerService(self)
         self._ps_service.serve()
 
+    def shutdown_parameter_servers(self):
+        """Ask every ps task to leave ``join()`` (for clusters whose strategy does not use them)."""
+        from .control import ControlClient
+        for j in range(self.num_ps):
+            host, port = self.control_address(j)
+            c = ControlClient(host, port, timeout_s=30.0)
+            c.push(("ps/req/%d" % j), b'{"op": "shutdown"}')
+            c.close()
+
     def stop(self):
         if self.control_server is not None:
             self.control_server.stop()
             self.control_server = None
         self._started = False
+
+    @staticmethod
+    def current() -> Optional["Server"]:
+        """The Server this process created (None in single-machine runs)."""
+        return _CURRENT_SERVER
 
     @staticmethod
     def create_local_server(config=None, start=True) -> "Server":

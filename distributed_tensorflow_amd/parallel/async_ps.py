@@ -226,10 +226,21 @@ class ParameterServerService:
 
     def serve(self):
         """Request loop; returns after a ``shutdown`` request."""
+        # the chief posts the layout; a cluster that trains without its ps tasks (synchronous replicas)
+        # only ever sends "shutdown"
+        layout = None
+        while layout is None:
+            try:
+                layout = self.cp.get_json("ps/layout", timeout_s=0.5)
+            except ControlTimeout:
+                if self.cp.qlen(self.queue) > 0:
+                    req = self.cp.pop_json(self.queue, timeout_s=1.0)
+                    if req.get("op") == "shutdown":
+                        self.cp.add("ps/stopped", 1)
+                        return
         if self.p2p is None:
-            self._join_data_plane()
+            self._join_data_plane()      # only clusters that use their ps tasks put them on the data plane
             self.p2p = _P2P(self.rank)
-        layout = self.cp.get_json("ps/layout")        # posted by the chief
         self._configure(layout)
         self.cp.add("ps/ready", 1)
         while True:
@@ -372,14 +383,6 @@ class AsyncPSStrategy:
         else:
             self._cps = [ControlClient(*srv.control_address(j), timeout_s=self.timeout_s) for j in range(self.num_owners)]
         self.cp0 = self._cps[0]
-        # data plane
-        if not dist.is_initialized():
-            host, port = srv.rendezvous_address()
-            backend = "nccl" if dev.type == "cuda" else "gloo"
-            world = self.num_workers if self.colocated else srv.world_size
-            rank = self.worker_index if self.colocated else srv.rank
-            init_process_group(backend, rank=rank, world_size=world, master_addr=host, master_port=port,
-                               device=dev if backend == "nccl" else None)
         self.my_rank = self.worker_index if self.colocated else srv.rank
         self.p2p = _P2P(self.my_rank)
         owner_rank = (lambda j: j) if self.colocated else srv.ps_rank
@@ -405,6 +408,14 @@ class AsyncPSStrategy:
             layout = {"ranges": self.ranges, "optimizer": opt_desc, "flat_len": store.flat_len}
             for j in sorted(set(range(self.num_owners))):
                 self._cps[j].set_json("ps/layout", layout)
+        # data plane (after the layout is out: ps tasks join the process group once they have it)
+        if not dist.is_initialized():
+            host, port = srv.rendezvous_address()
+            backend = "nccl" if dev.type == "cuda" else "gloo"
+            world = self.num_workers if self.colocated else srv.world_size
+            rank = self.worker_index if self.colocated else srv.rank
+            init_process_group(backend, rank=rank, world_size=world, master_addr=host, master_port=port,
+                               device=dev if backend == "nccl" else None)
         if self._service_thread is not None:
             self._service_thread.start()
         # chief initialises the owners, everybody else waits (chief-initialises / others-wait)
@@ -585,7 +596,17 @@ class AsyncPSStrategy:
             out.append(self._cps[j].get_json("ps/stats/%d" % j, timeout_s=self.timeout_s))
         return out
 
-    def shutdown_owners(self):
-        """Chief only: ends ``server.join()`` in every ps task (the reference has no such protocol)."""
+    def worker_done(self):
+        """Every worker calls this once after its last step."""
+        self.cp0.add("workers_done", 1)
+        self.cp0.clock_set("workers", self.worker_index, 1 << 60)   # a finished worker never holds others back
+
+    def shutdown_owners(self, wait_for_workers: bool = True):
+        """Chief only: ends ``server.join()`` in every ps task (the reference has no such protocol).
+        Waits until every worker has reported ``worker_done`` so nobody is cut off mid-step."""
+        if wait_for_workers:
+            t0 = time.time()
+            while self.cp0.add("workers_done", 0) < self.num_workers and time.time() - t0 < self.timeout_s:
+                time.sleep(0.02)
         for j in range(self.num_owners):
             self._cps[j].push_json("%s/%d" % (_REQ_QUEUE, j), {"op": "shutdown"})

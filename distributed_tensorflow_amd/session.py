@@ -147,14 +147,15 @@ class SummarySaverHook(SessionRunHook):
         self._next = session.global_step_value()
 
     def before_run(self, run_context):
-        self._want = self.summary_op is not None and run_context.session.global_step_value() >= self._next
+        self._pre_step = run_context.session.global_step_value()
+        self._want = self.summary_op is not None and self._pre_step >= self._next
         return SessionRunArgs(fetches=self.summary_op) if self._want else None
 
     def after_run(self, run_context, run_values):
         if self._want and self.writer is not None and run_values.results is not None:
             step = run_context.session.global_step_value()
             self.writer.add_summary(run_values.results, step)
-            self._next = step + self.save_steps
+            self._next = self._pre_step + self.save_steps
 
     def end(self, session):
         if self.writer is not None:
@@ -168,6 +169,7 @@ class CheckpointSaverHook(SessionRunHook):
                  saver=None, checkpoint_basename: str = "model.ckpt"):
         self.dir, self.save_secs, self.save_steps, self.saver = checkpoint_dir, save_secs, save_steps, saver
         self.basename = checkpoint_basename
+        self.poll_steps = 100
         self._last_time = None
         self._last_step = None
         self.saved_steps: List[int] = []
@@ -195,6 +197,13 @@ class CheckpointSaverHook(SessionRunHook):
             return
         due = (self.save_secs is not None and time.time() - self._last_time >= self.save_secs) or \
               (self.save_steps is not None and step - self._last_step >= self.save_steps)
+        agree = getattr(s.engine.strategy, "agree", None)
+        if agree is not None and getattr(s.engine.strategy, "collective_checkpoint", False):
+            # synchronous replicas save collectively: every replica runs this hook and follows the chief's
+            # clock, consulted every `poll_steps` steps so that the broadcast stays off the per-step path
+            if step % self.poll_steps != 0:
+                return
+            due = agree(due)
         if due and step != self._last_step:
             self._save(s, step)
 
@@ -395,6 +404,10 @@ def MonitoredTrainingSession(master: str = "", is_chief: bool = True, checkpoint
     all_hooks: List[SessionRunHook] = []
     if is_chief and chief_only_hooks:
         all_hooks.extend(chief_only_hooks)
+    collective = bool(getattr(getattr(engine, "strategy", None), "collective_checkpoint", False))
+    if (not is_chief) and checkpoint_dir and collective and save_checkpoint_secs:
+        all_hooks.append(CheckpointSaverHook(checkpoint_dir, save_secs=save_checkpoint_secs,
+                                             saver=scaffold.saver if scaffold else None))
     if is_chief and checkpoint_dir:
         if log_step_count_steps:
             all_hooks.append(StepCounterHook(every_n_steps=log_step_count_steps, output_dir=checkpoint_dir, log=None))

@@ -1,0 +1,118 @@
+"""MonitoredTrainingSession + hooks on the Sequential engine: stop, checkpoints, summaries, step counter, recovery."""
+import glob
+import os
+
+import pytest
+import torch
+
+from distributed_tensorflow_amd import session as ss
+from distributed_tensorflow_amd import summary as sm
+from distributed_tensorflow_amd.data import get_data
+from distributed_tensorflow_amd.engine import ACCURACY, GLOBAL_STEP, LOSS, TRAIN_OP, ModelEngine
+from distributed_tensorflow_amd.models import xor_mlp
+from distributed_tensorflow_amd.saver import latest_checkpoint
+
+
+def make(seed=0):
+    m = xor_mlp()
+    m.compile(loss="mean_squared_error", optimizer="adam", metrics=["binary_rounded_accuracy"], device="cpu", seed=seed)
+    return m, ModelEngine(m)
+
+
+DATA = get_data(500, val_set_size=100, seed=0)
+
+
+def loop(sess, n=10 ** 9):
+    xt, yt = DATA[0], DATA[1]
+    i = 0
+    while not sess.should_stop() and i < n:
+        lo = (i * 50) % 450
+        sess.run([LOSS, ACCURACY, TRAIN_OP], {"x": xt[lo:lo + 50], "y": yt[lo:lo + 50]})
+        i += 1
+    return i
+
+
+def test_stop_at_step_absolute_and_relative(tmp_path):
+    m, eng = make()
+    with ss.MonitoredTrainingSession(engine=eng, hooks=[ss.StopAtStepHook(last_step=25)]) as sess:
+        assert loop(sess) == 25 and sess.global_step_value() == 25
+    with ss.MonitoredTrainingSession(engine=eng, hooks=[ss.StopAtStepHook(num_steps=5)]) as sess:
+        assert loop(sess) == 5 and sess.global_step_value() == 30
+    with pytest.raises(ValueError):
+        ss.StopAtStepHook()
+
+
+def test_chief_default_hooks_write_files(tmp_path):
+    sm.reset_collection()
+    sm.FileWriterCache.clear()
+    m, eng = make()
+    sm.scalar("loss", lambda: eng._last_logs.get("loss", 0.0))
+    d = str(tmp_path)
+    with ss.MonitoredTrainingSession(engine=eng, is_chief=True, checkpoint_dir=d, hooks=[ss.StopAtStepHook(last_step=250)],
+                                     save_checkpoint_secs=600, save_summaries_steps=100, log_step_count_steps=100) as sess:
+        loop(sess)
+    sm.FileWriterCache.clear()
+    assert latest_checkpoint(d).endswith("model.ckpt-250")
+    assert os.path.exists(os.path.join(d, "model.ckpt-1.index"))        # saved right after the first step, too
+    (ev_path,) = glob.glob(os.path.join(d, "events.out.tfevents.*"))
+    ev = [e for e in sm.read_events(ev_path) if "scalars" in e]
+    assert sorted(e["step"] for e in ev if "loss" in e["scalars"]) == [1, 101, 201]
+    assert sorted(e["step"] for e in ev if "global_step/sec" in e["scalars"]) == [100, 200]
+    sm.reset_collection()
+
+
+def test_non_chief_writes_nothing(tmp_path):
+    m, eng = make()
+    with ss.MonitoredTrainingSession(engine=eng, is_chief=False, checkpoint_dir=str(tmp_path),
+                                     hooks=[ss.StopAtStepHook(last_step=5)]) as sess:
+        loop(sess)
+    assert os.listdir(str(tmp_path)) == []
+
+
+def test_resume_restores_variables_slots_and_step(tmp_path):
+    d = str(tmp_path)
+    m, eng = make(seed=0)
+    with ss.MonitoredTrainingSession(engine=eng, checkpoint_dir=d, hooks=[ss.StopAtStepHook(last_step=20)]) as sess:
+        loop(sess)
+    flat, mslot = m.store.flat.clone(), m.store.slot("m").clone()
+    m2, eng2 = make(seed=123)
+    with ss.MonitoredTrainingSession(engine=eng2, checkpoint_dir=d, hooks=[ss.StopAtStepHook(last_step=20)]) as sess:
+        assert sess.global_step_value() == 20 and sess.should_stop()     # budget already spent: nothing runs
+        assert torch.equal(m2.store.flat, flat) and torch.equal(m2.store.slot("m"), mslot)
+        assert abs(m2.store.beta_powers[0].item() - 0.9 ** 20) < 1e-6
+
+
+def test_recoverable_error_restores_last_checkpoint_and_retries(tmp_path):
+    d = str(tmp_path)
+    m, eng = make()
+    fault = ss.FaultInjectionHook(at_step=12, error=ss.AbortedError)
+    hooks = [ss.CheckpointSaverHook(d, save_secs=None, save_steps=5), fault, ss.StopAtStepHook(last_step=20)]
+    with ss.MonitoredSession(eng, checkpoint_dir=d, hooks=hooks, recovery_wait_secs=0.0) as sess:
+        n = loop(sess)
+        assert fault.fired and sess._recoveries == 1
+        assert sess.global_step_value() == 20
+    # steps 11 and 12 were lost with the fault (last checkpoint at 11: saves at 1, 6, 11) and redone
+    assert n == 20 + 1
+    assert latest_checkpoint(d).endswith("model.ckpt-20")
+
+
+def test_fatal_error_propagates_and_skips_end_hooks(tmp_path):
+    m, eng = make()
+    ck = ss.CheckpointSaverHook(str(tmp_path), save_secs=None, save_steps=1000)
+    with pytest.raises(ZeroDivisionError):
+        with ss.MonitoredSession(eng, hooks=[ck, ss.FaultInjectionHook(at_step=3, error=ZeroDivisionError)]) as sess:
+            loop(sess)
+    assert ck.saved_steps == [1]           # no final save after a crash
+
+
+def test_logging_and_nan_hooks():
+    m, eng = make()
+    lines = []
+    hooks = [ss.LoggingTensorHook({"step": GLOBAL_STEP}, every_n_iter=2, log=lines.append), ss.StopAtStepHook(last_step=4)]
+    with ss.MonitoredSession(eng, hooks=hooks) as sess:
+        loop(sess)
+    assert lines == ["INFO: step = 1", "INFO: step = 3"]    # fetched with the train op: the value after the update
+    m.store.flat.fill_(float("nan"))
+    with pytest.raises(FloatingPointError):
+        with ss.MonitoredSession(eng, hooks=[ss.NanLossHook(LOSS)]) as sess:
+            loop(sess, 1)
