@@ -7,7 +7,8 @@ an unseeded ``random.randint`` into Python lists; here the draw is vectorised, s
 and can be produced directly on the GPU.
 
 ``mnist_like`` makes MNIST-shaped data (784 floats in [0,1), 10 classes) whose labels come
-from a fixed random teacher network, so "test accuracy" on it is a meaningful number.
+class-conditionally: ten fixed random "stroke" prototypes, mixed with a distractor class and uniform pixel
+noise, so "test accuracy" on held-out samples is a meaningful number.
 """
 from __future__ import annotations
 
@@ -37,15 +38,17 @@ def get_data(n: int, bits: int = BITS, val_set_size: int = VAL_SET_SIZE, seed: O
 
 def mnist_like(n: int, seed: int = 0, device=None, num_classes: int = 10, input_dim: int = 784,
                one_hot: bool = False, teacher_seed: int = 1234) -> Tuple[torch.Tensor, torch.Tensor]:
-    """``n`` synthetic MNIST-shaped examples: x ~ U[0,1)^784, label = argmax of a fixed random teacher."""
+    """``n`` synthetic MNIST-shaped examples: each image is a noisy mixture of its label's prototype, a
+    distractor prototype and uniform pixel noise, clipped to [0, 1]."""
     dev = torch.device(device) if device is not None else torch.device("cpu")
     g = torch.Generator(device="cpu").manual_seed(int(teacher_seed))
-    w1 = torch.randn(input_dim, 32, generator=g) / (input_dim ** 0.5)
-    w2 = torch.randn(32, num_classes, generator=g)
+    protos = (torch.rand(num_classes, input_dim, generator=g) < 0.19).float()   # fixed "stroke" masks, ~19 % ink
     gx = torch.Generator(device="cpu").manual_seed(int(seed) + 17)
-    x = torch.rand(n, input_dim, generator=gx)
-    logits = torch.tanh((x - 0.5) @ w1 * 4.0) @ w2
-    y = logits.argmax(dim=1)
+    y = torch.randint(0, num_classes, (n,), generator=gx)
+    other = torch.randint(0, num_classes, (n,), generator=gx)
+    mix = torch.rand(n, 1, generator=gx) * 0.45                 # up to 45 % of a distractor class bleeds in
+    x = (1.0 - mix) * protos[y] + mix * protos[other]
+    x = (0.55 * x + 0.45 * torch.rand(n, input_dim, generator=gx)).clamp_(0.0, 1.0)
     x, y = x.to(dev), y.to(dev)
     if one_hot:
         y = torch.nn.functional.one_hot(y, num_classes).to(torch.float32)

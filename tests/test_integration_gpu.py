@@ -1,0 +1,140 @@
+"""End-to-end runs on one MI355X: convergence of the reference workload, hipGraph replay, RCCL path, checkpoints."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from distributed_tensorflow_amd.data import get_data, mnist_like
+from distributed_tensorflow_amd.models import mnist_mlp, xor_mlp
+from distributed_tensorflow_amd.ops import functional as F
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_native_library_is_what_runs(gpu_device):
+    from distributed_tensorflow_amd.ops import _native
+    _native.kernels()
+    maps = open("/proc/self/maps").read()
+    assert "libdtf_kernels.so" in maps
+
+
+def test_gpu_matches_cpu_reference_training(gpu_device):
+    """Same seeds, same batches: the HIP path and the PyTorch CPU reference stay together for 20 steps."""
+    xt, yt = get_data(1000, val_set_size=0, seed=3)[:2]
+    models = []
+    for dev in (gpu_device, torch.device("cpu")):
+        m = xor_mlp()
+        m.compile(loss="mean_squared_error", optimizer="adam", metrics=["binary_rounded_accuracy"], device=dev, seed=5)
+        models.append(m)
+    g, c = models
+    for lg, lc in zip(g.layers, c.layers):      # same dropout streams
+        if hasattr(lg, "seed"):
+            lc.seed = lg.seed
+    for i in range(20):
+        xb, yb = xt[i * 50:(i + 1) * 50], yt[i * 50:(i + 1) * 50]
+        g.train_step(xb.to(gpu_device), yb.to(gpu_device))
+        c.train_step(xb, yb)
+    torch.testing.assert_close(g.store.flat.cpu(), c.store.flat, rtol=2e-3, atol=2e-5)
+    lg, lc = g.read_stats(), c.read_stats()
+    assert abs(lg["loss"] - lc["loss"]) < 1e-4 and abs(lg["acc"] - lc["acc"]) < 2e-3
+
+
+def test_reference_workload_converges_with_graph_replay(gpu_device):
+    """The reference run: B=50, 600 steps/epoch, 50 epochs = 30000 steps, Adam 1e-3, dropout 0.3.
+    Validation accuracy (rounded bits, dropout off) must reach the plateau of the CPU proxy (0.93)."""
+    xt, yt, xv, yv = get_data(30000, seed=1, device=gpu_device)
+    m = xor_mlp()
+    m.compile(loss="mean_squared_error", optimizer="adam", metrics=["binary_rounded_accuracy"], device=gpu_device, seed=0)
+    h = m.fit(xt, yt, epochs=50, batch_size=50, validation_data=(xv, yv), verbose=0, steps_per_graph=100)
+    assert m.global_step == 30000
+    assert h.history["val_acc"][-1] >= 0.93, h.history["val_acc"][-5:]
+    assert h.history["val_acc"][4] > 0.85
+
+
+def test_graph_replay_equals_eager(gpu_device):
+    xt, yt = get_data(2000, val_set_size=0, seed=2, device=gpu_device)[:2]
+    res = []
+    for spg in (0, 10):
+        m = xor_mlp()
+        for l in m.layers:
+            if hasattr(l, "seed"):
+                l.seed = 77 + len(res) * 0
+        m.compile(loss="mean_squared_error", optimizer="adam", metrics=["binary_rounded_accuracy"], device=gpu_device, seed=9)
+        seeds = [getattr(l, "seed", None) for l in m.layers]
+        res.append((m, seeds))
+    a, b = res[0][0], res[1][0]
+    for la, lb in zip(a.layers, b.layers):
+        if hasattr(la, "seed"):
+            lb.seed = la.seed
+    ha = a.fit(xt, yt, epochs=2, batch_size=50, shuffle=False, verbose=0, steps_per_graph=0)
+    hb = b.fit(xt, yt, epochs=2, batch_size=50, shuffle=False, verbose=0, steps_per_graph=10)
+    assert a.global_step == b.global_step == 80
+    torch.testing.assert_close(a.store.flat, b.store.flat, rtol=1e-5, atol=1e-7)
+    assert abs(ha.history["loss"][-1] - hb.history["loss"][-1]) < 1e-6
+
+
+def test_mnist_mlp_learns_and_checkpoints(gpu_device, tmp_path):
+    from distributed_tensorflow_amd.saver import Saver, list_variables
+    x, y = mnist_like(16384, seed=0, device=gpu_device)
+    xt, yt = mnist_like(4096, seed=1, device=gpu_device)
+    m = mnist_mlp()
+    m.compile(loss="sparse_categorical_crossentropy", optimizer="adam", metrics=["accuracy"], device=gpu_device, seed=0)
+    h = m.fit(x, y, epochs=8, batch_size=256, validation_data=(xt, yt), verbose=0)
+    assert h.history["loss"][-1] < h.history["loss"][0]
+    assert h.history["val_acc"][-1] > 0.5
+    s = Saver(m.store, m.optimizer)
+    prefix = s.save(str(tmp_path / "model.ckpt"), global_step=m.global_step)
+    names = dict(list_variables(prefix))
+    assert names["dense_1/kernel"] == (784, 128) and names["dense_3/kernel"] == (128, 10)
+    m2 = mnist_mlp()
+    m2.compile(loss="sparse_categorical_crossentropy", optimizer="adam", metrics=["accuracy"], device=gpu_device, seed=1)
+    Saver(m2.store, m2.optimizer).restore(prefix)
+    assert torch.equal(m2.store.flat, m.store.flat)
+    assert m2.evaluate(xt, yt, batch_size=1024)[1] == pytest.approx(h.history["val_acc"][-1], abs=1e-6)
+
+
+def test_rccl_path_single_rank(gpu_device, tmp_path):
+    """The sync-replica strategy with real RCCL calls (reduce-scatter / all-gather / broadcast) on a 1-rank group
+    must equal the local strategy."""
+    code = r'''
+import os, sys, torch
+sys.path.insert(0, %r)
+os.environ["DTF_FORCE_COLLECTIVES"] = "1"
+from distributed_tensorflow_amd.data import mnist_like
+from distributed_tensorflow_amd.models import mnist_mlp
+from distributed_tensorflow_amd.parallel import Communicator, SyncReplicasStrategy, init_process_group
+dev = torch.device("cuda", 0)
+init_process_group("nccl", rank=0, world_size=1, master_addr="127.0.0.1", master_port=%d, device=dev)
+x, y = mnist_like(4096, seed=0, device=dev)
+outs = []
+for strat in (None, SyncReplicasStrategy(Communicator(), bucket_bytes=1 << 16)):
+    m = mnist_mlp()
+    for i, l in enumerate(m.layers):
+        if hasattr(l, "seed"): l.seed = 100 + i
+    m.compile(loss="sparse_categorical_crossentropy", optimizer="adam", metrics=["accuracy"], strategy=strat, device=dev, seed=0)
+    for i in range(8):
+        m.train_step(x[i*512:(i+1)*512], y[i*512:(i+1)*512])
+    torch.cuda.synchronize()
+    outs.append([v.tensor.clone() for v in m.store.trainable] + [m.global_step])
+    if strat is not None:
+        assert len(strat.buckets) > 1
+for a, b in zip(outs[0][:-1], outs[1][:-1]):
+    torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-7)
+assert outs[0][-1] == outs[1][-1] == 8
+import torch.distributed as dist
+dist.destroy_process_group()
+print("RCCL_OK")
+''' % (ROOT, 29500 + os.getpid() % 1000)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "RCCL_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+def test_graph_style_example_on_gpu(tmp_path):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "example.py"), "--log_dir", str(tmp_path),
+                          "--last_step", "3000", "--seed", "1"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "Running single-machine training" in out.stdout and "Training complete!" in out.stdout
+    assert "Validation Accuracy:" in out.stdout
