@@ -37,6 +37,8 @@ def parse_args():
     ap.add_argument("--batch-per-gpu", type=int, default=0, help="0 = the model's default")
     ap.add_argument("--pool", type=int, default=4, help="distinct device-resident synthetic batches cycled through")
     ap.add_argument("--graph", type=int, default=-1, help="replay the step from a hipGraph (-1 = auto: single GPU only)")
+    ap.add_argument("--fused", type=int, default=-1,
+                    help="one-launch whole-step kernel for the small-batch reference MLP (-1 = when available, 0 = off)")
     ap.add_argument("--bucket-mb", type=float, default=64.0)
     ap.add_argument("--width", type=int, default=16384, help="wide_mlp hidden width")
     ap.add_argument("--depth", type=int, default=5, help="wide_mlp hidden depth")
@@ -94,32 +96,49 @@ def main():
     model.compile(loss=loss, optimizer="adam", metrics=["accuracy"], strategy=strategy, device=dev, seed=0)
 
     pool = max(1, args.pool)
+    # small-batch reference network on one GPU: the whole step (and runs of consecutive steps) is one launch
+    plan = model.fused_step_plan(B) if (args.fused != 0 and world == 1) else None
+    if args.fused == 1 and plan is None:
+        raise SystemExit("--fused 1: no fused step kernel for this model / batch / world size")
+    if plan is not None:
+        pool = max(pool, 128)
     x_all, y_all = make(B * pool, 1000 + rank)
     batches = [(x_all[i * B:(i + 1) * B], y_all[i * B:(i + 1) * B]) for i in range(pool)]
 
-    use_graph = (args.graph == 1) or (args.graph == -1 and world == 1)
+    use_graph = plan is None and ((args.graph == 1) or (args.graph == -1 and world == 1))
     graphs = None
     if use_graph:
         graphs = [model._graphed_steps(bx, by, B, 1) for bx, by in batches]
 
+    def run(first, count):
+        """Training steps first .. first+count-1; step i consumes batch i % pool."""
+        if plan is not None:
+            i = first
+            while i < first + count:
+                k = min(pool - i % pool, first + count - i)
+                off = (i % pool) * B
+                model.train_steps_fused(x_all[off:], y_all[off:], B, k, plan)
+                i += k
+            return
+        for i in range(first, first + count):
+            if graphs is not None:
+                graphs[i % pool].replay()
+            else:
+                bx, by = batches[i % pool]
+                model.train_step(bx, by)
+
     def step(i):
-        if graphs is not None:
-            graphs[i % pool].replay()
-        else:
-            bx, by = batches[i % pool]
-            model.train_step(bx, by)
+        run(i, 1)
 
     def fence():
         if world > 1:
             dist.barrier(device_ids=[dev.index])
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
+    run(0, args.warmup)
     fence()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
+    run(args.warmup, args.steps)
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -153,7 +172,7 @@ def main():
             "data": "synthetic (device-resident MNIST-shaped inputs, random-init weights)",
             "config": {"model": args.model, "global_batch": global_batch, "batch_per_gpu": B, "seq_len": None,
                        "parallelism": "dp%d" % world, "params": model.store.num_params,
-                       "optimizer": "adam", "hip_graph": bool(use_graph),
+                       "optimizer": "adam", "hip_graph": bool(use_graph), "fused_step_kernel": plan is not None,
                        "train_loss": logs.get("loss"), "train_acc": logs.get("acc"), "test_acc": test_acc},
         }
         print(json.dumps(out), flush=True)

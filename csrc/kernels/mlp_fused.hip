@@ -1,0 +1,578 @@
+// Whole-training-step kernel for the reference network at small batch:
+// 64 -> 128 relu -> dropout -> 128 relu -> dropout -> 32 sigmoid, MSE, Adam, batch 50
+// (/root/reference/example.py:149-170,207-213).
+//
+// At batch 50 a step is ~9 MFLOP: a chain of layer kernels is pure launch latency (eleven
+// dependent launches at ~1.5 us per boundary plus their fill/drain).  Here ONE workgroup of eight
+// waves (two per SIMD, so one wave's LDS / VALU / memory waits hide under the other's MFMAs) on
+// one CU runs forward, loss, backward and the optimizer update for `nsteps` consecutive
+// mini-batches in a single launch:
+//   * activations live in LDS for the whole step (x, h1, h2, p; dz2/dz1 overwrite h2/h1 in place);
+//   * weights stream L2 -> registers -> LDS in chunks, each chunk's loads issued one phase ahead so
+//     their latency hides under the previous phase's MFMAs; W1 never leaves LDS between steps (the
+//     W1 update writes its LDS image as well);
+//   * every GEMM runs on v_mfma_f32_32x32x2_f32 from LDS operands with the same k-permuted 16-byte
+//     fragment reads as the big GEMM kernel; each wave owns one 32x32 output tile per phase;
+//   * weight gradients never leave the accumulators: the wgrad epilogue applies Adam (or SGD)
+//     straight to the variable and its slots, whose old values were requested before the tile's
+//     MFMA loop.  Every layer's gradients are taken before that layer's update is visible
+//     (TensorFlow's compute-then-apply order);
+//   * loss / accuracy accumulate in registers and reach the statistics record once per launch;
+//   * dropout masks are the same counter-based function of (seed, global_step, index) as in the
+//     layer-wise kernels, so both paths draw identical masks; all sums have a fixed order.
+// Variables are read with sc1 (L2-served) loads: the CU re-reads values it stored one step earlier.
+#include "common.h"
+
+namespace {
+
+typedef unsigned int u32x4 __attribute__((vector_size(16)));
+
+constexpr int NT = 512;                      // threads: 8 waves
+constexpr int BM = 64;                       // batch rows held in LDS (batch <= 64)
+constexpr int D0 = 64, D1 = 128, D2 = 128, D3 = 32;
+constexpr int LX = D0 + 4, L1 = D1 + 4, L2 = D2 + 4, L3 = D3 + 4;   // LDS row strides (floats): stride/4 odd
+constexpr int LT = 64 + 4;                   // row stride of a 64-column slice of W2
+// Staging area images: W1 / a 64-row chunk of W2 as [64][132]; W3 as [128][36] followed by a [64][36] partial-sum
+// scratch; a 64-column slice of W2 as [128][68].
+constexpr int SW_FLOATS = 128 * LT;
+constexpr int W3_SCRATCH = D2 * L3;
+static_assert(64 * L2 <= SW_FLOATS && W3_SCRATCH + BM * L3 <= SW_FLOATS, "staging images must fit");
+constexpr int LDS_FLOATS = BM * LX + BM * L3 + BM * L1 + BM * L2 + BM * L3 + SW_FLOATS + 32 + D1 + D2 + D3;
+static_assert(LDS_FLOATS * 4 <= 160 * 1024, "activations + weight staging must fit one CU's LDS");
+
+struct FusedArgs {
+    const float* X;      // [nsteps * B, D0]
+    const float* Y;      // [nsteps * B, D3]
+    float* params;       // flat variable buffer
+    float* slot_m;       // Adam m (null for SGD)
+    float* slot_v;       // Adam v
+    long long off[6];    // element offsets of W1, b1, W2, b2, W3, b3 in the flat buffers
+    int B;
+    int nsteps;
+    int training;        // 1: dropout on
+    int want_cat;        // also count argmax(p) == argmax(y) rows into stats[3] (Keras 'accuracy' on a wide output)
+    float keep1, keep2;
+    uint32_t seed1, seed2;
+    float lr, beta1, beta2, eps;
+    long long* step_ptr;
+    float* beta_powers;  // [2] or null
+    float* stats;        // [4] running statistics or null
+    long long* prof;     // [16] shader-clock timestamps of the last step's phases, or null (profiling aid)
+};
+
+// Phase timestamp i of the launch's last step (thread 0 only; a scalar branch when profiling is off).
+#define DTF_PROF(i)                                                                                        \
+    do {                                                                                                   \
+        if (p.prof && tid0 == 0 && s == p.nsteps - 1) p.prof[i] = (long long)__builtin_readcyclecounter(); \
+    } while (0)
+
+__device__ __forceinline__ float ld1_sc1(const float* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- global -> register -> LDS staging -------------------------------------------------------
+// A [ROWS x COLS] block of a row-major matrix is ROWS*COLS/4 16-byte vectors; thread `tid` owns vectors tid,
+// tid+NT, ...  Loads go through a buffer resource of `bytes` bytes: reads past it return zero, which pads the batch
+// to BM rows without a branch.
+template <int ROWS, int COLS>
+struct Stage {
+    static constexpr int NV = ROWS * COLS / 4 / NT;
+    static_assert(NV * NT * 4 == ROWS * COLS, "block must split evenly over the workgroup");
+    f32x4 v[NV];
+
+    // `ld`: row stride of the source in floats; SC1: L2-served load
+    template <bool SC1>
+    __device__ __forceinline__ void issue(const float* base, unsigned bytes, int ld, int tid) {
+        __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)bytes, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + NT * i;
+            const int row = idx / (COLS / 4), c = (idx % (COLS / 4)) * 4;
+            const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(r, (row * ld + c) * 4, 0, SC1 ? 16 : 0);
+            v[i] = __builtin_bit_cast(f32x4, raw);
+        }
+    }
+    // dst is [ROWS][COLS + 4]
+    __device__ __forceinline__ void commit(float* dst, int tid) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + NT * i;
+            const int row = idx / (COLS / 4), c = (idx % (COLS / 4)) * 4;
+            *reinterpret_cast<f32x4*>(dst + row * (COLS + 4) + c) = v[i];
+        }
+    }
+};
+
+// One 32x32 output tile: acc += sum_k A(m,k) B(k,n), both operands in LDS.
+//   A_KC: A[m][k] row-major (k contiguous)   else A[k][m]
+//   B_KC: B[n][k] row-major (k contiguous)   else B[k][n]
+template <bool A_KC, bool B_KC, int K>
+__device__ __forceinline__ void tile_mma(f32x16& acc, const float* A, int lda, int m0, const float* B, int ldb, int n0,
+                                         int lane) {
+    const int li = lane & 31, h = lane >> 5;
+    const float* pa = A_KC ? A + (m0 + li) * lda + 4 * h : A + (4 * h) * lda + m0 + li;
+    const float* pb = B_KC ? B + (n0 + li) * ldb + 4 * h : B + (4 * h) * ldb + n0 + li;
+#pragma unroll 4
+    for (int kk = 0; kk < K; kk += 8) {
+        f32x4 a, b;
+        if (A_KC) {
+            a = *reinterpret_cast<const f32x4*>(pa + kk);
+        } else {
+            const float* q = pa + kk * lda;
+            a[0] = q[0]; a[1] = q[lda]; a[2] = q[2 * lda]; a[3] = q[3 * lda];
+        }
+        if (B_KC) {
+            b = *reinterpret_cast<const f32x4*>(pb + kk);
+        } else {
+            const float* q = pb + kk * ldb;
+            b[0] = q[0]; b[1] = q[ldb]; b[2] = q[2 * ldb]; b[3] = q[3 * ldb];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], acc, 0, 0, 0);
+    }
+}
+
+__device__ __forceinline__ void zero(f32x16& a) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = 0.f;
+}
+
+__device__ __forceinline__ int tile_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+struct Opt {
+    float lr, lr_t, b1, b2, eps;
+};
+
+// TF's Adam: var -= lr_t * m / (sqrt(v) + eps).  sqrt and reciprocal use the hardware approximations (1 ulp each).
+template <int OPT>
+__device__ __forceinline__ float opt_update(const Opt& o, float w, float& m, float& v, float g) {
+    if (OPT == 0) {
+        m = o.b1 * m + (1.0f - o.b1) * g;
+        v = o.b2 * v + (1.0f - o.b2) * g * g;
+        return w - o.lr_t * m * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) + o.eps);
+    }
+    return w - o.lr * g;
+}
+
+// The flat variable buffer and its slot buffers as buffer resources: 32-bit byte offsets instead of 64-bit
+// pointers per element (half the address registers and address arithmetic of flat accesses).
+struct VarBufs {
+    __amdgpu_buffer_rsrc_t w, m, v;
+};
+__device__ __forceinline__ float vb_load(__amdgpu_buffer_rsrc_t r, int byte_off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 16));   // sc1: L2-served
+}
+__device__ __forceinline__ void vb_store(__amdgpu_buffer_rsrc_t r, int byte_off, float x) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, x), r, byte_off, 0, 0);
+}
+
+// Old values of one 32x32 variable tile in the MFMA accumulator layout, requested ahead of use.
+template <int OPT>
+struct TileState {
+    float w[16], m[16], v[16];
+
+    __device__ __forceinline__ void issue(const VarBufs& vb, long long off, int N, int i0, int n0, int lane) {
+        const int li = lane & 31, h = lane >> 5;
+        const int base = ((int)off + (i0 + 4 * h) * N + n0 + li) * 4;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int bo = base + ((r & 3) + 8 * (r >> 2)) * N * 4;
+            w[r] = vb_load(vb.w, bo);
+            if (OPT == 0) {
+                m[r] = vb_load(vb.m, bo);
+                v[r] = vb_load(vb.v, bo);
+            }
+        }
+    }
+    // apply the gradient tile; `mirror` (optional) receives the new values as an LDS image [rows][ldm]
+    __device__ __forceinline__ void finish(const VarBufs& vb, const Opt& o, const f32x16& g, long long off, int N, int i0,
+                                           int n0, int lane, float* mirror, int ldm) {
+        const int li = lane & 31, h = lane >> 5;
+        const int base = ((int)off + (i0 + 4 * h) * N + n0 + li) * 4;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rr = (r & 3) + 8 * (r >> 2);
+            const int bo = base + rr * N * 4;
+            const float nw = opt_update<OPT>(o, w[r], m[r], v[r], g[r]);
+            vb_store(vb.w, bo, nw);
+            if (OPT == 0) {
+                vb_store(vb.m, bo, m[r]);
+                vb_store(vb.v, bo, v[r]);
+            }
+            if (mirror) mirror[(i0 + 4 * h + rr) * ldm + n0 + li] = nw;
+        }
+    }
+};
+
+// One bias element per thread (tid < N): old values requested early, gradient = column sum of dz (rows >= B are 0).
+template <int OPT>
+struct BiasState {
+    float w, m, v;
+    __device__ __forceinline__ void issue(const VarBufs& vb, long long off, int N, int tid) {
+        w = m = v = 0.f;
+        if (tid < N) {
+            const int bo = ((int)off + tid) * 4;
+            w = vb_load(vb.w, bo);
+            if (OPT == 0) {
+                m = vb_load(vb.m, bo);
+                v = vb_load(vb.v, bo);
+            }
+        }
+    }
+    // `mirror`: LDS copy of the bias that the next step's forward epilogue reads
+    __device__ __forceinline__ void finish(const VarBufs& vb, const Opt& o, const float* dz, int ld, long long off, int N,
+                                           int tid, float* mirror) {
+        if (tid < N) {
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll 4
+            for (int r = 0; r < BM; r += 4) {
+                s0 += dz[r * ld + tid];
+                s1 += dz[(r + 1) * ld + tid];
+                s2 += dz[(r + 2) * ld + tid];
+                s3 += dz[(r + 3) * ld + tid];
+            }
+            const int bo = ((int)off + tid) * 4;
+            const float nw = opt_update<OPT>(o, w, m, v, (s0 + s1) + (s2 + s3));
+            vb_store(vb.w, bo, nw);
+            if (OPT == 0) {
+                vb_store(vb.m, bo, m);
+                vb_store(vb.v, bo, v);
+            }
+            mirror[tid] = nw;
+        }
+    }
+};
+
+template <int OPT>
+__global__ __launch_bounds__(NT, 1) void mlp3_fused_kernel(const FusedArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* sX = lds;
+    float* sY = sX + BM * LX;
+    float* sH1 = sY + BM * L3;
+    float* sH2 = sH1 + BM * L1;
+    float* sP = sH2 + BM * L2;
+    float* sW = sP + BM * L3;
+    float* sRed = sW + SW_FLOATS;   // 32 floats
+    float* sB1 = sRed + 32;         // current biases (D1 + D2 + D3 floats)
+    float* sB2 = sB1 + D1;
+    float* sB3 = sB2 + D2;
+
+    const int tid0 = threadIdx.x;
+    int tid = tid0;
+    const int B = p.B;
+    const long long step0 = *p.step_ptr;
+    float loss_acc = 0.f, acc_acc = 0.f, cat_acc = 0.f;
+    float b1_pow = 1.f, b2_pow = 1.f;
+    const bool drop1 = p.training && p.keep1 < 1.0f, drop2 = p.training && p.keep2 < 1.0f;
+    const float sc1 = drop1 ? 1.0f / p.keep1 : 1.0f, sc2 = drop2 ? 1.0f / p.keep2 : 1.0f;
+    const unsigned W_BYTES = 0x7FFFFFF0u;
+    VarBufs vb;
+    vb.w = __builtin_amdgcn_make_buffer_rsrc(p.params, 0, (int)W_BYTES, 0x00020000);
+    vb.m = __builtin_amdgcn_make_buffer_rsrc(OPT == 0 ? p.slot_m : p.params, 0, (int)W_BYTES, 0x00020000);
+    vb.v = __builtin_amdgcn_make_buffer_rsrc(OPT == 0 ? p.slot_v : p.params, 0, (int)W_BYTES, 0x00020000);
+
+    Stage<64, 128> pw;             // W1, a 64-row chunk of W2 (forward)
+    Stage<128, 64> pt;             // a 64-column slice of W2 (dgrad)
+    Stage<128, 32> pw3;            // W3
+    Stage<BM, D0> px;              // next batch
+    Stage<BM, D3> py;
+
+    px.template issue<false>(p.X, (unsigned)B * D0 * 4, D0, tid);
+    py.template issue<false>(p.Y, (unsigned)B * D3 * 4, D3, tid);
+    pw.template issue<true>(p.params + p.off[0], W_BYTES, D1, tid);
+    pw.commit(sW, tid);            // W1 image; later steps find it already there
+    if (tid < D1) sB1[tid] = ld1_sc1(p.params + p.off[1] + tid);
+    if (tid < D2) sB2[tid] = ld1_sc1(p.params + p.off[3] + tid);
+    if (tid < D3) sB3[tid] = ld1_sc1(p.params + p.off[5] + tid);
+
+    for (int s = 0; s < p.nsteps; ++s) {
+        // The thread index is made opaque once per step: every address and dropout-hash term below is step-invariant,
+        // and hoisting them all out of this loop would cost far more registers than recomputing them.
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int li = lane & 31, h = lane >> 5;
+        const int tm = wave >> 2, tn = wave & 3;       // this wave's tile of a [64 x 128] output
+        const int col = tn * 32 + li;
+        const long long step = step0 + s;
+        DTF_PROF(0);
+        Opt o;
+        o.lr = p.lr; o.b1 = p.beta1; o.b2 = p.beta2; o.eps = p.eps;
+        if ((s & 63) == 0) {           // beta^t as running products, re-based every 64 steps: powf costs hundreds of
+            b1_pow = powf(p.beta1, (float)step);    // instructions
+            b2_pow = powf(p.beta2, (float)step);
+        }
+        b1_pow *= p.beta1;
+        b2_pow *= p.beta2;
+        o.lr_t = p.lr * sqrtf(1.0f - b2_pow) / (1.0f - b1_pow);
+        const uint32_t key1 = dtf_dropout_key(p.seed1, &step), key2 = dtf_dropout_key(p.seed2, &step);
+
+        // ---- batch -> LDS
+        px.commit(sX, tid);
+        py.commit(sY, tid);
+        __syncthreads();
+        DTF_PROF(1);
+        const float bf1 = sB1[col], bf2 = sB2[col], bf3 = sB3[tid & 31];
+
+        // ---- L1: h1 = dropout(relu(x W1 + b1))
+        pw.template issue<true>(p.params + p.off[2], W_BYTES, D2, tid);                 // W2 rows 0..63
+        {
+            f32x16 acc; zero(acc);
+            tile_mma<true, false, D0>(acc, sX, LX, tm * 32, sW, L1, tn * 32, lane);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = tm * 32 + tile_row(r, h);
+                float v = fmaxf(acc[r] + bf1, 0.f);
+                if (drop1) v = (dtf_uniform(key1, (unsigned long long)row * (unsigned)D1 + col) < p.keep1) ? v * sc1 : 0.f;
+                sH1[row * L1 + col] = v;
+            }
+        }
+        __syncthreads();
+        DTF_PROF(2);
+        // ---- L2: h2 = dropout(relu(h1 W2 + b2)); two k-chunks of 64
+        pw.commit(sW, tid);
+        pw.template issue<true>(p.params + p.off[2] + 64 * D2, W_BYTES, D2, tid);       // W2 rows 64..127
+        __syncthreads();
+        f32x16 acc2; zero(acc2);
+        tile_mma<true, false, 64>(acc2, sH1, L1, tm * 32, sW, L2, tn * 32, lane);
+        __syncthreads();
+        DTF_PROF(3);
+        pw.commit(sW, tid);
+        pw3.template issue<true>(p.params + p.off[4], W_BYTES, D3, tid);                // W3
+        __syncthreads();
+        tile_mma<true, false, 64>(acc2, sH1 + 64, L1, tm * 32, sW, L2, tn * 32, lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = tm * 32 + tile_row(r, h);
+            float v = fmaxf(acc2[r] + bf2, 0.f);
+            if (drop2) v = (dtf_uniform(key2, (unsigned long long)row * (unsigned)D2 + col) < p.keep2) ? v * sc2 : 0.f;
+            sH2[row * L2 + col] = v;
+        }
+        __syncthreads();
+        DTF_PROF(4);
+        // ---- L3: p = sigmoid(h2 W3 + b3).  The W3 image [128][36] serves forward (B[k][n]) and dgrad (B[n'][k'],
+        //      n' = input unit, k' = output unit) alike.  Two row tiles x two k-halves on waves 0..3; the halves meet
+        //      in the elementwise pass below (fixed order).
+        pw3.commit(sW, tid);
+        __syncthreads();
+        if (wave < 4) {
+            const int rt = wave & 1, kh = wave >> 1;
+            f32x16 acc; zero(acc);
+            tile_mma<true, false, 64>(acc, sH2 + kh * 64, L2, rt * 32, sW + kh * 64 * L3, L3, 0, lane);
+            float* dst = kh ? sW + W3_SCRATCH : sP;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[(rt * 32 + tile_row(r, h)) * L3 + li] = acc[r];
+        }
+        __syncthreads();
+        DTF_PROF(5);
+        // ---- sigmoid, loss, metrics, dz3 (in place of p); rows >= B become zero.  Element e = tid + NT*i:
+        //      row = e / 32, column = tid & 31.
+        {
+            float pv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = (tid >> 5) + 16 * i, c = tid & 31;
+                pv[i] = dtf_sigmoid(sP[row * L3 + c] + sW[W3_SCRATCH + row * L3 + c] + bf3);
+            }
+            if (p.want_cat) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sP[((tid >> 5) + 16 * i) * L3 + (tid & 31)] = pv[i];
+                __syncthreads();
+                if (tid < B) {
+                    int bp = 0, by = 0;
+                    float vp = sP[tid * L3], vy = sY[tid * L3];
+                    for (int c = 1; c < D3; ++c) {
+                        const float a = sP[tid * L3 + c], b = sY[tid * L3 + c];
+                        if (a > vp) { vp = a; bp = c; }
+                        if (b > vy) { vy = b; by = c; }
+                    }
+                    cat_acc += (bp == by) ? 1.f : 0.f;
+                }
+                __syncthreads();
+            }
+            const float gs = 2.0f / ((float)B * (float)D3);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = (tid >> 5) + 16 * i, c = tid & 31;
+                float dz = 0.f;
+                if (row < B) {
+                    const float yv = sY[row * L3 + c], d = pv[i] - yv;
+                    loss_acc += d * d;
+                    acc_acc += (rintf(pv[i]) == rintf(yv)) ? 1.f : 0.f;
+                    dz = gs * d * pv[i] * (1.0f - pv[i]);
+                }
+                sP[row * L3 + c] = dz;
+            }
+        }
+        __syncthreads();
+        DTF_PROF(6);
+
+        // ---- dW3 = h2^T dz3 (waves 0..3: input-unit block = wave) and the dz2 products, both reading h2
+        TileState<OPT> ts;
+        BiasState<OPT> bs3, bs2, bs1;
+        if (wave < 4) ts.issue(vb, p.off[4], D3, wave * 32, 0, lane);
+        bs3.issue(vb, p.off[5], D3, tid);
+        bs2.issue(vb, p.off[3], D2, tid);
+        bs1.issue(vb, p.off[1], D1, tid);
+        pt.template issue<true>(p.params + p.off[2], W_BYTES, D2, tid);                 // W2 columns 0..63
+        f32x16 g3; zero(g3);
+        if (wave < 4) tile_mma<false, false, BM>(g3, sH2, L2, wave * 32, sP, L3, 0, lane);
+        f32x16 az; zero(az);
+        tile_mma<true, true, D3>(az, sP, L3, tm * 32, sW, L3, tn * 32, lane);
+        __syncthreads();                                                                // every reader of h2 is done
+        DTF_PROF(7);
+        // ---- dz2 = (dz3 W3^T) * (h2 > 0) / keep2, in place of h2; apply W3 and b3
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = tm * 32 + tile_row(r, h);
+            const float y = sH2[row * L2 + col];
+            sH2[row * L2 + col] = (y > 0.f) ? az[r] * sc2 : 0.f;
+        }
+        __syncthreads();                                                                // dz2 complete, W3 image free
+        DTF_PROF(8);
+
+        // ---- dW2 = h1^T dz2 held in registers: tiles t = wave, wave + 8 (input block t >> 2, output block t & 3).
+        //      Waves 0..3 first apply W3 / b3 (VALU + memory) while their SIMD partners 4..7 already run MFMAs.
+        pt.commit(sW, tid);
+        pt.template issue<true>(p.params + p.off[2] + 64, W_BYTES, D2, tid);            // W2 columns 64..127
+        if (wave < 4) ts.finish(vb, o, g3, p.off[4], D3, wave * 32, 0, lane, nullptr, 0);
+        bs3.finish(vb, o, sP, L3, p.off[5], D3, tid, sB3);
+        f32x16 g2[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            zero(g2[q]);
+            const int t = wave + 8 * q;
+            tile_mma<false, false, BM>(g2[q], sH1, L1, (t >> 2) * 32, sH2, L2, (t & 3) * 32, lane);
+        }
+        bs2.finish(vb, o, sH2, L2, p.off[3], D2, tid, sB2);
+        __syncthreads();                                                                // h1 readers done; slice 0 visible
+        DTF_PROF(9);
+        // ---- dz1 = (dz2 W2^T) * (h1 > 0) / keep1 in place of h1, summed over two 64-wide slices of W2's columns
+        {
+            f32x16 a1; zero(a1);
+            tile_mma<true, true, 64>(a1, sH2, L2, tm * 32, sW, LT, tn * 32, lane);
+            __syncthreads();
+            pt.commit(sW, tid);
+            __syncthreads();
+            tile_mma<true, true, 64>(a1, sH2 + 64, L2, tm * 32, sW, LT, tn * 32, lane);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = tm * 32 + tile_row(r, h);
+                const float y = sH1[row * L1 + col];
+                sH1[row * L1 + col] = (y > 0.f) ? a1[r] * sc1 : 0.f;
+            }
+        }
+        __syncthreads();        // dz1 complete; every wave's W2 loads have landed (each committed its own); sW is free
+        DTF_PROF(10);
+        // ---- apply W2 from the held accumulators, and dW1 = x^T dz1 applied directly (input block tm, output block
+        //      tn; new W1 mirrored into its LDS image).  The two waves of a SIMD take the two jobs in opposite order,
+        //      so one's update arithmetic and memory traffic overlap the other's MFMAs.
+        if (s + 1 < p.nsteps) {
+            px.template issue<false>(p.X + (long long)(s + 1) * B * D0, (unsigned)B * D0 * 4, D0, tid);
+            py.template issue<false>(p.Y + (long long)(s + 1) * B * D3, (unsigned)B * D3 * 4, D3, tid);
+        }
+        {
+            const int i2a = (wave >> 2) * 32, i2b = ((wave + 8) >> 2) * 32, n2 = (wave & 3) * 32;
+            TileState<OPT> t1, t2;
+            if (wave < 4) {
+                t2.issue(vb, p.off[2], D2, i2a, n2, lane);
+                t1.issue(vb, p.off[0], D1, tm * 32, tn * 32, lane);
+                t2.finish(vb, o, g2[0], p.off[2], D2, i2a, n2, lane, nullptr, 0);
+                t2.issue(vb, p.off[2], D2, i2b, n2, lane);
+                f32x16 acc; zero(acc);
+                tile_mma<false, false, BM>(acc, sX, LX, tm * 32, sH1, L1, tn * 32, lane);
+                t2.finish(vb, o, g2[1], p.off[2], D2, i2b, n2, lane, nullptr, 0);
+                t1.finish(vb, o, acc, p.off[0], D1, tm * 32, tn * 32, lane, sW, L1);
+            } else {
+                t1.issue(vb, p.off[0], D1, tm * 32, tn * 32, lane);
+                t2.issue(vb, p.off[2], D2, i2a, n2, lane);
+                f32x16 acc; zero(acc);
+                tile_mma<false, false, BM>(acc, sX, LX, tm * 32, sH1, L1, tn * 32, lane);
+                t2.finish(vb, o, g2[0], p.off[2], D2, i2a, n2, lane, nullptr, 0);
+                t2.issue(vb, p.off[2], D2, i2b, n2, lane);
+                t1.finish(vb, o, acc, p.off[0], D1, tm * 32, tn * 32, lane, sW, L1);
+                t2.finish(vb, o, g2[1], p.off[2], D2, i2b, n2, lane, nullptr, 0);
+            }
+        }
+        DTF_PROF(11);
+        bs1.finish(vb, o, sH1, L1, p.off[1], D1, tid, sB1);
+        // every wave's variable stores must have reached L2 before the next step requests them again
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        DTF_PROF(12);
+    }
+
+    // ---- once per launch: statistics, global_step, beta powers
+    const int lane = tid0 & 63, wave = tid0 >> 6;
+    if (p.stats) {
+        const float l = dtf_wave_sum(loss_acc), a = dtf_wave_sum(acc_acc), c = dtf_wave_sum(cat_acc);
+        if (lane == 0) { sRed[wave] = l; sRed[8 + wave] = a; sRed[16 + wave] = c; }
+        __syncthreads();
+        if (tid0 == 0) {
+            float sl = 0.f, sa = 0.f, sc = 0.f;
+            for (int w = 0; w < NT / 64; ++w) { sl += sRed[w]; sa += sRed[8 + w]; sc += sRed[16 + w]; }
+            const float inv = 1.0f / (float)D3;
+            atomicAdd(p.stats + 0, sl * inv);
+            atomicAdd(p.stats + 1, sa * inv);
+            atomicAdd(p.stats + 2, (float)B * (float)p.nsteps);
+            if (p.want_cat) atomicAdd(p.stats + 3, sc);
+        }
+    }
+    if (tid0 == 0) {
+        *p.step_ptr = step0 + p.nsteps;
+        if (p.beta_powers && OPT == 0) {
+            p.beta_powers[0] *= powf(p.beta1, (float)p.nsteps);
+            p.beta_powers[1] *= powf(p.beta2, (float)p.nsteps);
+        }
+    }
+}
+
+long long* g_prof_buffer = nullptr;
+
+}  // namespace
+
+// Profiling aid: device buffer of 16 int64 that receives shader-clock timestamps of the phases of each launch's
+// last step (null switches it off).
+DTF_API int dtf_mlp3_fused_set_profile_buffer(long long* device_buffer) {
+    g_prof_buffer = device_buffer;
+    return 0;
+}
+
+// Supported shape of this build: (64, 128, 128, 32) - the reference network - at batch <= 64.
+DTF_API int dtf_mlp3_fused_supported(int d0, int d1, int d2, int d3, int B) {
+    return (d0 == D0 && d1 == D1 && d2 == D2 && d3 == D3 && B >= 1 && B <= BM) ? 1 : 0;
+}
+
+// nsteps full training steps (relu, relu, sigmoid; MSE; Adam when opt == 0, SGD when opt == 1) on consecutive
+// mini-batches X[k*B:(k+1)*B], Y[k*B:(k+1)*B].
+DTF_API int dtf_mlp3_fused_train(const float* X, const float* Y, float* params, float* slot_m, float* slot_v,
+                                 const long long* offsets6, int d0, int d1, int d2, int d3, int B, int nsteps,
+                                 int training, int opt, int want_cat, float keep1, float keep2, uint32_t seed1,
+                                 uint32_t seed2, float lr, float beta1, float beta2, float eps, long long* step_ptr,
+                                 float* beta_powers, float* stats, hipStream_t stream) {
+    if (!dtf_mlp3_fused_supported(d0, d1, d2, d3, B)) return -4;
+    if (opt == 0 && (!slot_m || !slot_v)) return -5;
+    if (opt != 0 && opt != 1) return -6;
+    if (nsteps <= 0) return 0;
+    FusedArgs a = {};
+    a.X = X; a.Y = Y; a.params = params; a.slot_m = slot_m; a.slot_v = slot_v;
+    for (int i = 0; i < 6; ++i) a.off[i] = offsets6[i];
+    a.B = B; a.nsteps = nsteps; a.training = training; a.want_cat = want_cat;
+    a.keep1 = keep1; a.keep2 = keep2; a.seed1 = seed1; a.seed2 = seed2;
+    a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
+    a.step_ptr = step_ptr; a.beta_powers = beta_powers; a.stats = stats; a.prof = g_prof_buffer;
+    constexpr size_t lds = sizeof(float) * LDS_FLOATS;
+    static bool once = false;
+    if (!once) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp3_fused_kernel<0>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp3_fused_kernel<1>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        once = true;
+    }
+    if (opt == 0) hipLaunchKernelGGL(mlp3_fused_kernel<0>, dim3(1), dim3(NT), lds, stream, a);
+    else hipLaunchKernelGGL(mlp3_fused_kernel<1>, dim3(1), dim3(NT), lds, stream, a);
+    DTF_CHECK_LAUNCH();
+    return 0;
+}

@@ -137,7 +137,11 @@ class ModelEngine:
             if need_stats:
                 m.stats.zero_()
             if training:
-                m.train_step(xd, yd)
+                plan = m.fused_step_plan(int(xd.shape[0])) if hasattr(m, "fused_step_plan") else None
+                if plan is not None:
+                    m.train_steps_fused(xd, yd, int(xd.shape[0]), 1, plan)     # the whole step in one launch
+                else:
+                    m.train_step(xd, yd)
             else:
                 # learning phase 0 with a training op: update without dropout
                 out = m.forward(xd, training=False)

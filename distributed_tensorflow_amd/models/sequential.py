@@ -76,6 +76,7 @@ class Sequential:
         self._grad_buf: Dict = {}
         self._host_step = 0           # host mirror of global_step (no device sync needed)
         self._graphs: Dict = {}
+        self._fused_plans: Dict = {}
         self._after_layer_backward = None   # strategy hook: called as each layer's gradients become final
         for layer in layers or []:
             self.add(layer)
@@ -298,6 +299,58 @@ class Sequential:
         self._graphs[key] = g
         return g
 
+    # ------------------------------------------------------------------ whole-step kernel
+    def fused_step_plan(self, batch_size: int):
+        """Arguments for the one-launch training step (``csrc/kernels/mlp_fused.hip``) when this model is the
+        reference network shape (Dense relu [+Dropout], Dense relu [+Dropout], Dense sigmoid; MSE; Adam or plain
+        SGD; single replica; batch <= 64) and runs on the GPU; ``None`` otherwise."""
+        if not self.compiled or self.device is None or self.device.type != "cuda":
+            return None
+        if type(self.strategy) is not LocalStrategy or self._after_layer_backward is not None:
+            return None
+        key = (int(batch_size), id(self.optimizer))
+        if key not in self._fused_plans:
+            self._fused_plans[key] = self._make_fused_step_plan(batch_size)
+        return self._fused_plans[key]
+
+    def _make_fused_step_plan(self, batch_size: int):
+        eff = self._effective
+        if len(eff) != 3 or not all(isinstance(l, Dense) and l.bias is not None and not l.softmax for l in eff):
+            return None
+        if [l.act for l in eff] != [ACT_RELU, ACT_RELU, ACT_SIGMOID] or eff[2].fused_keep < 1.0:
+            return None
+        if any(isinstance(l, Dropout) and not l.fused_into_previous and l.rate > 0.0 for l in self.layers):
+            return None
+        if not isinstance(self.loss, losses_mod.MeanSquaredError):
+            return None
+        opt = self.optimizer
+        if isinstance(opt, optim_mod.Adam):
+            kind = 0
+            m, v = self.store.slot("m"), self.store.slot("v")
+        elif isinstance(opt, optim_mod.SGD) and opt.momentum == 0.0:
+            kind = 1
+            m = v = None
+        else:
+            return None
+        dims = (eff[0].kernel.shape[0], eff[0].units, eff[1].units, eff[2].units)
+        if not F.mlp3_fused_supported(dims, batch_size):
+            return None
+        offsets = [x.offset for l in eff for x in (l.kernel, l.bias)]
+        return dict(dims=dims, offsets=offsets, opt=kind, m=m, v=v, l1=eff[0], l2=eff[1])
+
+    def train_steps_fused(self, x_buf: torch.Tensor, y_buf: torch.Tensor, batch_size: int, nsteps: int, plan=None):
+        """``nsteps`` training steps on ``x_buf[k*B:(k+1)*B]`` in a single kernel launch."""
+        plan = plan or self.fused_step_plan(batch_size)
+        if plan is None:
+            raise RuntimeError("this model / batch size has no fused step kernel")
+        st, opt, l1, l2 = self.store, self.optimizer, plan["l1"], plan["l2"]
+        hp = (opt.lr, opt.beta1, opt.beta2, opt.epsilon) if plan["opt"] == 0 else (opt.lr, 0.0, 0.0, 0.0)
+        # hyper-parameters, keep probabilities and dropout seeds are read at call time, like the layer-wise path does
+        F.mlp3_fused_train(x_buf, y_buf, st.flat, plan["m"], plan["v"], plan["offsets"], plan["dims"], batch_size,
+                           nsteps, True, plan["opt"], self._extra_categorical, l1.fused_keep, l2.fused_keep,
+                           l1.seed, l2.seed, *hp, st.global_step, st.beta_powers, self.stats)
+        self._host_step += nsteps
+
     def _snapshot(self):
         st = self.store
         return (st.flat.clone(), {k: v.clone() for k, v in st.slots.items()}, st.global_step.clone(),
@@ -314,11 +367,14 @@ class Sequential:
 
     # ------------------------------------------------------------------ fit
     def fit(self, x, y, epochs: int = 1, batch_size: int = 32, validation_data=None, callbacks=None,
-            shuffle: bool = True, verbose: int = 1, steps_per_graph: int = 0, initial_epoch: int = 0):
+            shuffle: bool = True, verbose: int = 1, steps_per_graph: int = 0, initial_epoch: int = 0,
+            fused: Optional[bool] = None):
         """Keras ``fit``.  Data is moved to the device once; each epoch reshuffles on the device.
 
         ``steps_per_graph > 0`` (GPU only) replays that many consecutive steps from one
-        captured hipGraph; 0 launches every kernel eagerly.
+        captured hipGraph; 0 launches every kernel eagerly.  ``fused`` (default: automatic) selects the
+        one-launch whole-step kernel when the model has one (``fused_step_plan``); ``False`` forces the
+        layer-by-layer path.
         """
         self._check_compiled()
         xd, yd = _as_tensor(x, self.device), _as_tensor(y, self.device)
@@ -334,7 +390,10 @@ class Sequential:
         cl = cb.CallbackList(cbs, self, params)
         self.stop_training = False
         cl.call("on_train_begin", None)
-        use_graph = steps_per_graph > 0 and self.device.type == "cuda"
+        plan = self.fused_step_plan(batch_size) if fused in (None, True) else None
+        if fused and plan is None:
+            raise RuntimeError("fused=True but this model / batch size has no fused step kernel")
+        use_graph = steps_per_graph > 0 and self.device.type == "cuda" and plan is None
         x_ep = torch.empty_like(xd) if (shuffle or use_graph) else xd
         y_ep = torch.empty_like(yd) if (shuffle or use_graph) else yd
         full_steps = n // batch_size
@@ -351,7 +410,22 @@ class Sequential:
                 y_ep.copy_(yd)
             self.stats.zero_()
             done = 0
-            if use_graph:
+            if plan is not None:
+                chunk = full_steps if not cl.wants_batch_logs else max(steps_per_graph, 1)
+                while done < full_steps:
+                    k = min(chunk, full_steps - done)
+                    off = done * batch_size
+                    self.train_steps_fused(x_ep[off:], y_ep[off:], batch_size, k, plan)
+                    done += k
+                    if cl.wants_batch_logs:
+                        cl.call("on_batch_end", done - 1, {})
+                if done < steps:        # ragged last batch
+                    off = done * batch_size
+                    self.train_steps_fused(x_ep[off:], y_ep[off:], n - off, 1)
+                    done += 1
+                    if cl.wants_batch_logs:
+                        cl.call("on_batch_end", done - 1, {})
+            elif use_graph:
                 while full_steps - done >= steps_per_graph:
                     off = done * batch_size
                     span = steps_per_graph * batch_size

@@ -67,6 +67,9 @@ def kernels():
         "dtf_scale": [c_p, c_ll, c_f, c_p],
         "dtf_activation": [c_p, c_p, c_ll, c_i, c_p],
         "dtf_softmax_rows": [c_p, c_p, c_i, c_i, c_p],
+        "dtf_mlp3_fused_supported": [c_i, c_i, c_i, c_i, c_i],
+        "dtf_mlp3_fused_train": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
+                                 c_f, c_f, c_u32, c_u32, c_f, c_f, c_f, c_f, c_p, c_p, c_p, c_p],
     }
     for name, argtypes in sig.items():
         if hasattr(lib, name):

@@ -374,3 +374,39 @@ def xor_data(n, bits, seed, device):
     x[:, bits:] = b.to(torch.float32)
     y.copy_((a ^ b).to(torch.float32))
     return x, y
+
+
+def mlp3_fused_supported(dims, batch: int) -> bool:
+    """True when the whole-step kernel (csrc/kernels/mlp_fused.hip) covers a 3-layer MLP of these widths."""
+    if len(dims) != 4 or not nv.kernels_available():
+        return False
+    lib = nv.kernels()
+    return hasattr(lib, "dtf_mlp3_fused_supported") and bool(lib.dtf_mlp3_fused_supported(*map(int, dims), int(batch)))
+
+
+def mlp3_fused_train(x, y, params, slot_m, slot_v, offsets, dims, batch, nsteps, training, opt, want_cat, keep1, keep2,
+                     seed1, seed2, lr, beta1, beta2, eps, step, beta_powers, stats):
+    """``nsteps`` complete training steps (forward, MSE, backward, Adam/SGD update) of the reference MLP in ONE
+    launch on mini-batches ``x[k*batch:(k+1)*batch]``; GPU only.  ``offsets``: element offsets of
+    W1, b1, W2, b2, W3, b3 inside ``params`` (and the slot buffers)."""
+    import ctypes as C
+    nv.require_f32_contig(x, y, params, slot_m, slot_v)
+    if not x.is_cuda:
+        raise ValueError("the fused step kernel runs on the GPU only")
+    if x.shape[0] < batch * nsteps or y.shape[0] < batch * nsteps or x.shape[1] != dims[0] or y.shape[1] != dims[3]:
+        raise ValueError("fused step: data %s/%s does not hold %d batches of %d x %s" %
+                         (tuple(x.shape), tuple(y.shape), nsteps, batch, (dims[0], dims[3])))
+    need = max(offsets[0] + dims[0] * dims[1], offsets[2] + dims[1] * dims[2], offsets[4] + dims[2] * dims[3],
+               offsets[1] + dims[1], offsets[3] + dims[2], offsets[5] + dims[3])
+    for t in (params, slot_m, slot_v):
+        if t is not None and t.numel() < need:
+            raise ValueError("fused step: flat buffer of %d elements is shorter than the layout (%d)" % (t.numel(), need))
+    if any(o % 4 for o in offsets):
+        raise ValueError("fused step: variable offsets must be multiples of 4 elements")
+    offs = (C.c_longlong * 6)(*[int(o) for o in offsets])
+    rc = nv.kernels().dtf_mlp3_fused_train(
+        nv.ptr(x), nv.ptr(y), nv.ptr(params), nv.ptr(slot_m), nv.ptr(slot_v), C.cast(offs, C.c_void_p),
+        int(dims[0]), int(dims[1]), int(dims[2]), int(dims[3]), int(batch), int(nsteps), int(bool(training)), int(opt),
+        int(bool(want_cat)), float(keep1), float(keep2), int(seed1) & _M32, int(seed2) & _M32, float(lr), float(beta1),
+        float(beta2), float(eps), nv.ptr(step), nv.ptr(beta_powers), nv.ptr(stats), nv.stream_ptr())
+    nv.check(rc, "dtf_mlp3_fused_train")

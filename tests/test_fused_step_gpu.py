@@ -1,0 +1,102 @@
+"""The one-launch training step (csrc/kernels/mlp_fused.hip) against the layer-by-layer HIP path and the CPU
+reference: same seeds -> same dropout masks -> same variables, slots, statistics and step counters."""
+import pytest
+import torch
+
+from distributed_tensorflow_amd.data import get_data
+from distributed_tensorflow_amd.layers import Dense, Dropout
+from distributed_tensorflow_amd.models import Sequential, xor_mlp
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(device, optimizer="adam", metrics=("binary_rounded_accuracy",), devices=None):
+    ms = []
+    for dev in (devices or (device, device)):
+        m = xor_mlp()
+        m.compile(loss="mean_squared_error", optimizer=optimizer, metrics=list(metrics), device=dev, seed=5)
+        ms.append(m)
+    for m in ms:                       # fixed dropout streams: the comparison is reproducible run to run
+        for i, l in enumerate(m.layers):
+            if hasattr(l, "seed"):
+                l.seed = 4242 + 17 * i
+    return ms
+
+
+def test_plan_detection(gpu_device):
+    m = xor_mlp()
+    m.compile(loss="mean_squared_error", optimizer="adam", device=gpu_device, seed=0)
+    plan = m.fused_step_plan(50)
+    assert plan is not None and plan["dims"] == (64, 128, 128, 32) and plan["l1"].fused_keep == pytest.approx(0.7)
+    assert m.fused_step_plan(65) is None                       # batch beyond the LDS-resident tile
+    other = Sequential([Dense(64, input_dim=64, activation="relu"), Dense(32, activation="sigmoid")])
+    other.compile(loss="mean_squared_error", optimizer="adam", device=gpu_device, seed=0)
+    assert other.fused_step_plan(50) is None
+    with pytest.raises(RuntimeError):
+        other.fit(torch.zeros(100, 64), torch.zeros(100, 32), batch_size=50, epochs=1, verbose=0, fused=True)
+
+
+@pytest.mark.parametrize("optimizer", ["adam", "sgd"])
+def test_fused_equals_layerwise(gpu_device, optimizer):
+    """Both paths compute the same sums in different orders, so they agree to rounding.  Adam on a ReLU network is
+    not a contraction: one pre-activation within rounding distance of zero flips a mask and moves a rarely-active
+    weight by ~10 learning rates, so the long run is compared through its loss and the bulk of the weights, and the
+    strict element-wise comparison is made over the first 20 steps."""
+    xt, yt = get_data(2000, val_set_size=0, seed=2, device=gpu_device)[:2]
+    a, b = _pair(gpu_device, optimizer)
+    for i in range(20):
+        a.train_step(xt[i * 50:(i + 1) * 50], yt[i * 50:(i + 1) * 50])
+    b.train_steps_fused(xt, yt, 50, 20)
+    assert a.global_step == b.global_step == 20
+    torch.testing.assert_close(a.store.flat, b.store.flat, rtol=2e-4, atol=2e-6)
+    for k in a.store.slots:
+        torch.testing.assert_close(a.store.slots[k], b.store.slots[k], rtol=2e-4, atol=1e-9)
+    torch.testing.assert_close(a.store.beta_powers, b.store.beta_powers, rtol=1e-5, atol=0)
+    a.stats.zero_()
+    b.stats.zero_()
+    ha = a.fit(xt, yt, epochs=2, batch_size=50, shuffle=False, verbose=0, fused=False)
+    hb = b.fit(xt, yt, epochs=2, batch_size=50, shuffle=False, verbose=0, fused=True)
+    assert a.global_step == b.global_step == 100
+    d = (a.store.flat - b.store.flat).abs()
+    assert float((d > 1e-4).float().mean()) < 0.01 and float(d.median()) < 1e-6
+    assert ha.history["loss"][-1] == pytest.approx(hb.history["loss"][-1], rel=1e-3)
+    assert ha.history["acc"][-1] == pytest.approx(hb.history["acc"][-1], abs=2e-3)
+
+
+def test_fused_ragged_last_batch_and_keras_accuracy(gpu_device):
+    xt, yt = get_data(130, val_set_size=0, seed=4, device=gpu_device)[:2]     # 50 + 50 + 30
+    a, b = _pair(gpu_device, metrics=("accuracy", "binary_rounded_accuracy"))
+    ha = a.fit(xt, yt, epochs=3, batch_size=50, shuffle=False, verbose=0, fused=False)
+    hb = b.fit(xt, yt, epochs=3, batch_size=50, shuffle=False, verbose=0)     # automatic selection
+    assert a.global_step == b.global_step == 9
+    torch.testing.assert_close(a.store.flat, b.store.flat, rtol=2e-4, atol=2e-6)
+    for key in ("loss", "acc", "binary_rounded_accuracy"):
+        assert ha.history[key][-1] == pytest.approx(hb.history[key][-1], rel=1e-4, abs=1e-6), key
+
+
+def test_fused_matches_cpu_reference(gpu_device):
+    xt, yt = get_data(500, val_set_size=0, seed=7)[:2]
+    g, c = _pair(gpu_device, devices=(gpu_device, torch.device("cpu")))
+    g.train_steps_fused(xt.to(gpu_device), yt.to(gpu_device), 50, 10)
+    for i in range(10):
+        c.train_step(xt[i * 50:(i + 1) * 50], yt[i * 50:(i + 1) * 50])
+    torch.testing.assert_close(g.store.flat.cpu(), c.store.flat, rtol=2e-3, atol=2e-5)
+    lg, lc = g.read_stats(), c.read_stats()
+    assert lg["loss"] == pytest.approx(lc["loss"], abs=1e-4) and lg["acc"] == pytest.approx(lc["acc"], abs=2e-3)
+    assert g.global_step == 10
+
+
+def test_fused_no_dropout_and_tiny_batch(gpu_device):
+    ms = []
+    for _ in range(2):
+        m = Sequential([Dense(128, input_dim=64, activation="relu"), Dense(128, activation="relu"),
+                        Dense(32, activation="sigmoid")])
+        m.compile(loss="mean_squared_error", optimizer="adam", device=gpu_device, seed=11)
+        ms.append(m)
+    a, b = ms
+    xt, yt = get_data(64, val_set_size=0, seed=9, device=gpu_device)[:2]
+    for i in range(8):
+        a.train_step(xt[i * 8:(i + 1) * 8], yt[i * 8:(i + 1) * 8])
+    b.train_steps_fused(xt, yt, 8, 8)
+    torch.testing.assert_close(a.store.flat, b.store.flat, rtol=2e-4, atol=2e-6)
+    assert a.global_step == b.global_step == 8

@@ -42,13 +42,17 @@ def test_gpu_matches_cpu_reference_training(gpu_device):
     assert abs(lg["loss"] - lc["loss"]) < 1e-4 and abs(lg["acc"] - lc["acc"]) < 2e-3
 
 
-def test_reference_workload_converges_with_graph_replay(gpu_device):
+@pytest.mark.parametrize("path", ["fused_step_kernel", "graph_replay"])
+def test_reference_workload_converges(gpu_device, path):
     """The reference run: B=50, 600 steps/epoch, 50 epochs = 30000 steps, Adam 1e-3, dropout 0.3.
-    Validation accuracy (rounded bits, dropout off) must reach the plateau of the CPU proxy (0.93)."""
+    Validation accuracy (rounded bits, dropout off) must reach the plateau of the CPU proxy (0.93), through the
+    one-launch step kernel and through hipGraph replay of the layer-by-layer step."""
     xt, yt, xv, yv = get_data(30000, seed=1, device=gpu_device)
     m = xor_mlp()
     m.compile(loss="mean_squared_error", optimizer="adam", metrics=["binary_rounded_accuracy"], device=gpu_device, seed=0)
-    h = m.fit(xt, yt, epochs=50, batch_size=50, validation_data=(xv, yv), verbose=0, steps_per_graph=100)
+    assert m.fused_step_plan(50) is not None
+    h = m.fit(xt, yt, epochs=50, batch_size=50, validation_data=(xv, yv), verbose=0, steps_per_graph=100,
+              fused=(path == "fused_step_kernel"))
     assert m.global_step == 30000
     assert h.history["val_acc"][-1] >= 0.93, h.history["val_acc"][-5:]
     assert h.history["val_acc"][4] > 0.85
@@ -69,8 +73,8 @@ def test_graph_replay_equals_eager(gpu_device):
     for la, lb in zip(a.layers, b.layers):
         if hasattr(la, "seed"):
             lb.seed = la.seed
-    ha = a.fit(xt, yt, epochs=2, batch_size=50, shuffle=False, verbose=0, steps_per_graph=0)
-    hb = b.fit(xt, yt, epochs=2, batch_size=50, shuffle=False, verbose=0, steps_per_graph=10)
+    ha = a.fit(xt, yt, epochs=2, batch_size=50, shuffle=False, verbose=0, steps_per_graph=0, fused=False)
+    hb = b.fit(xt, yt, epochs=2, batch_size=50, shuffle=False, verbose=0, steps_per_graph=10, fused=False)
     assert a.global_step == b.global_step == 80
     torch.testing.assert_close(a.store.flat, b.store.flat, rtol=1e-5, atol=1e-7)
     assert abs(ha.history["loss"][-1] - hb.history["loss"][-1]) < 1e-6
