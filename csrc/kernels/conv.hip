@@ -1,0 +1,201 @@
+// Convolution support kernels (NHWC): patch matrix build / scatter-back and max pooling.
+//
+// conv2d runs as "patch matrix x filter matrix" on the MFMA GEMM kernels: a Keras/TF filter variable
+// [KH, KW, Cin, Cout] IS the row-major [KH*KW*Cin, Cout] GEMM operand, and the GEMM output
+// [B*OH*OW, Cout] IS the NHWC activation, so no transposes are ever materialised and the fused
+// bias / activation / bias-gradient epilogues of the dense path apply unchanged.  With 288 GB of HBM
+// the patch matrix is kept for the backward pass (wgrad reads it again) instead of being rebuilt.
+#include "common.h"
+
+namespace {
+
+struct ConvGeom {
+    int B, H, W, C;        // input
+    int KH, KW, OH, OW;    // window, output
+    int pad_t, pad_l, sh, sw;
+};
+
+// cols[m][(kh*KW + kw)*C + c] = x[b][oh*sh - pad_t + kh][ow*sw - pad_l + kw][c]  (zero outside the image)
+template <int V>
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x, float* __restrict__ cols,
+                                                     const ConvGeom g, long long total) {
+    const int K = g.KH * g.KW * g.C;
+    const int KV = K / V;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const long long m = idx / KV;
+        const int k = (int)(idx - m * KV) * V;
+        const int c = k % g.C;
+        const int kw = (k / g.C) % g.KW;
+        const int kh = k / (g.C * g.KW);
+        const int ow = (int)(m % g.OW);
+        const int oh = (int)((m / g.OW) % g.OH);
+        const int b = (int)(m / ((long long)g.OW * g.OH));
+        const int ih = oh * g.sh - g.pad_t + kh, iw = ow * g.sw - g.pad_l + kw;
+        const bool in = ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
+        const long long src = (((long long)b * g.H + ih) * g.W + iw) * g.C + c;
+        if (V == 4) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (in) v = *reinterpret_cast<const f32x4*>(x + src);
+            *reinterpret_cast<f32x4*>(cols + m * K + k) = v;
+        } else {
+            cols[m * K + k] = in ? x[src] : 0.f;
+        }
+    }
+}
+
+// dx[b][ih][iw][c] = sum over (kh, kw) of dcols[(b, oh, ow)][(kh*KW + kw)*C + c] with oh*sh - pad_t + kh == ih (same for w);
+// optionally times the producing layer's ReLU gradient (yprev > 0).
+template <int V>
+__global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ dcols, float* __restrict__ dx,
+                                                     const float* __restrict__ yprev, const ConvGeom g, long long total) {
+    const int K = g.KH * g.KW * g.C;
+    const int CV = g.C / V;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int c = (int)(idx % CV) * V;
+        const long long pix = idx / CV;
+        const int iw = (int)(pix % g.W);
+        const int ih = (int)((pix / g.W) % g.H);
+        const int b = (int)(pix / ((long long)g.W * g.H));
+        float acc[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] = 0.f;
+        for (int kh = 0; kh < g.KH; ++kh) {
+            const int th = ih + g.pad_t - kh;
+            if (th < 0 || th % g.sh) continue;
+            const int oh = th / g.sh;
+            if (oh >= g.OH) continue;
+            for (int kw = 0; kw < g.KW; ++kw) {
+                const int tw = iw + g.pad_l - kw;
+                if (tw < 0 || tw % g.sw) continue;
+                const int ow = tw / g.sw;
+                if (ow >= g.OW) continue;
+                const long long m = ((long long)b * g.OH + oh) * g.OW + ow;
+                const float* src = dcols + m * K + (kh * g.KW + kw) * g.C + c;
+                if (V == 4) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(src);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j] += v[j];
+                } else {
+                    acc[0] += src[0];
+                }
+            }
+        }
+        const long long dst = pix * g.C + c;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            float r = acc[j];
+            if (yprev) r = yprev[dst + j] > 0.f ? r : 0.f;
+            dx[dst + j] = r;
+        }
+    }
+}
+
+struct PoolGeom {
+    int B, H, W, C, PH, PW, OH, OW;   // non-overlapping windows (stride == window), VALID padding
+};
+
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          unsigned char* __restrict__ arg, const PoolGeom g, long long total) {
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int c = (int)(idx % g.C);
+        const long long pix = idx / g.C;
+        const int ow = (int)(pix % g.OW);
+        const int oh = (int)((pix / g.OW) % g.OH);
+        const int b = (int)(pix / ((long long)g.OW * g.OH));
+        float best = -INFINITY;
+        int bi = 0;
+        for (int i = 0; i < g.PH; ++i)
+            for (int j = 0; j < g.PW; ++j) {
+                const float v = x[(((long long)b * g.H + oh * g.PH + i) * g.W + ow * g.PW + j) * g.C + c];
+                if (v > best) { best = v; bi = i * g.PW + j; }
+            }
+        y[idx] = best;
+        arg[idx] = (unsigned char)bi;
+    }
+}
+
+// dx = dy routed to each window's arg-max position; optionally times the ReLU gradient of the pooled tensor (x > 0)
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ arg,
+                                                          const float* __restrict__ x_relu, float* __restrict__ dx,
+                                                          const PoolGeom g, long long total) {
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int c = (int)(idx % g.C);
+        const long long pix = idx / g.C;
+        const int iw = (int)(pix % g.W);
+        const int ih = (int)((pix / g.W) % g.H);
+        const int b = (int)(pix / ((long long)g.W * g.H));
+        const int oh = ih / g.PH, ow = iw / g.PW;
+        float r = 0.f;
+        if (oh < g.OH && ow < g.OW) {
+            const long long o = (((long long)b * g.OH + oh) * g.OW + ow) * g.C + c;
+            if ((int)arg[o] == (ih - oh * g.PH) * g.PW + (iw - ow * g.PW)) r = dy[o];
+        }
+        if (x_relu && !(x_relu[idx] > 0.f)) r = 0.f;
+        dx[idx] = r;
+    }
+}
+
+inline int grid_for(long long total) {
+    long long blocks = (total + 255) / 256;
+    const long long cap = 256 * 32;      // grid-stride beyond 32 blocks per CU
+    return (int)(blocks < 1 ? 1 : (blocks > cap ? cap : blocks));
+}
+
+bool geom_ok(const ConvGeom& g) {
+    // every image access is bounds-checked in the kernels; the caller sizes cols as [B*OH*OW, KH*KW*C]
+    return g.B > 0 && g.H > 0 && g.W > 0 && g.C > 0 && g.KH > 0 && g.KW > 0 && g.OH > 0 && g.OW > 0 && g.sh > 0 &&
+           g.sw > 0 && g.pad_t >= 0 && g.pad_l >= 0;
+}
+
+}  // namespace
+
+DTF_API int dtf_im2col(const float* x, float* cols, int B, int H, int W, int C, int KH, int KW, int OH, int OW, int pad_t,
+                       int pad_l, int sh, int sw, hipStream_t stream) {
+    const ConvGeom g = {B, H, W, C, KH, KW, OH, OW, pad_t, pad_l, sh, sw};
+    if (!geom_ok(g)) return -3;
+    const long long M = (long long)B * OH * OW, K = (long long)KH * KW * C;
+    if (C % 4 == 0) {
+        const long long total = M * (K / 4);
+        hipLaunchKernelGGL(im2col_kernel<4>, dim3(grid_for(total)), dim3(256), 0, stream, x, cols, g, total);
+    } else {
+        const long long total = M * K;
+        hipLaunchKernelGGL(im2col_kernel<1>, dim3(grid_for(total)), dim3(256), 0, stream, x, cols, g, total);
+    }
+    DTF_CHECK_LAUNCH();
+    return 0;
+}
+
+DTF_API int dtf_col2im(const float* dcols, float* dx, const float* yprev, int B, int H, int W, int C, int KH, int KW, int OH,
+                       int OW, int pad_t, int pad_l, int sh, int sw, hipStream_t stream) {
+    const ConvGeom g = {B, H, W, C, KH, KW, OH, OW, pad_t, pad_l, sh, sw};
+    if (!geom_ok(g)) return -3;
+    if (C % 4 == 0) {
+        const long long total = (long long)B * H * W * (C / 4);
+        hipLaunchKernelGGL(col2im_kernel<4>, dim3(grid_for(total)), dim3(256), 0, stream, dcols, dx, yprev, g, total);
+    } else {
+        const long long total = (long long)B * H * W * C;
+        hipLaunchKernelGGL(col2im_kernel<1>, dim3(grid_for(total)), dim3(256), 0, stream, dcols, dx, yprev, g, total);
+    }
+    DTF_CHECK_LAUNCH();
+    return 0;
+}
+
+DTF_API int dtf_maxpool_fwd(const float* x, float* y, unsigned char* arg, int B, int H, int W, int C, int PH, int PW,
+                            hipStream_t stream) {
+    if (B <= 0 || H < PH || W < PW || C <= 0 || PH <= 0 || PW <= 0 || PH * PW > 255) return -3;
+    const PoolGeom g = {B, H, W, C, PH, PW, H / PH, W / PW};
+    const long long total = (long long)B * g.OH * g.OW * C;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, y, arg, g, total);
+    DTF_CHECK_LAUNCH();
+    return 0;
+}
+
+DTF_API int dtf_maxpool_bwd(const float* dy, const unsigned char* arg, const float* x_relu, float* dx, int B, int H, int W,
+                            int C, int PH, int PW, hipStream_t stream) {
+    if (B <= 0 || H < PH || W < PW || C <= 0 || PH <= 0 || PW <= 0 || PH * PW > 255) return -3;
+    const PoolGeom g = {B, H, W, C, PH, PW, H / PH, W / PW};
+    const long long total = (long long)B * H * W * C;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, dy, arg, x_relu, dx, g, total);
+    DTF_CHECK_LAUNCH();
+    return 0;
+}

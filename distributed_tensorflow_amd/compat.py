@@ -544,6 +544,14 @@ class _Flatten(_SymbolicLayerMixin, _layers.Flatten):
     pass
 
 
+class _Conv2D(_SymbolicLayerMixin, _layers.Conv2D):
+    pass
+
+
+class _MaxPooling2D(_SymbolicLayerMixin, _layers.MaxPooling2D):
+    pass
+
+
 class _KerasBackend:
     _session = None
 
@@ -570,7 +578,8 @@ def _keras_mse(y_true, y_pred):
 
 
 keras = types.SimpleNamespace(
-    layers=types.SimpleNamespace(Dense=_Dense, Dropout=_Dropout, Activation=_Activation, Flatten=_Flatten),
+    layers=types.SimpleNamespace(Dense=_Dense, Dropout=_Dropout, Activation=_Activation, Flatten=_Flatten,
+                                 Conv2D=_Conv2D, MaxPooling2D=_MaxPooling2D),
     models=types.SimpleNamespace(Sequential=_Sequential),
     backend=_KerasBackend,
     losses=types.SimpleNamespace(mean_squared_error=_keras_mse),

@@ -251,3 +251,175 @@ class Flatten(Layer):
 
     def backward(self, dy):
         return dy.reshape(self._in_shape)
+
+
+def _pair(v) -> Tuple[int, int]:
+    if isinstance(v, (tuple, list)):
+        if len(v) != 2:
+            raise ValueError("expected an int or a pair, got %r" % (v,))
+        return int(v[0]), int(v[1])
+    return int(v), int(v)
+
+
+class Conv2D(Layer):
+    """NHWC 2-D convolution, ``y = activation(conv(x, kernel) + bias)``; kernel is ``[kh, kw, cin, cout]`` as in
+    TF/Keras checkpoints.
+
+    Executed as patch matrix x filter matrix on the MFMA GEMM kernels: the kernel variable viewed as
+    ``[kh*kw*cin, cout]`` is the GEMM's B operand as stored, the GEMM output ``[B*OH*OW, cout]`` is the NHWC result as
+    stored, and bias / activation / bias-gradient ride in the GEMM epilogues exactly as for ``Dense``.  The patch
+    matrix is kept from forward to backward (wgrad reads it), then reused as the buffer of the patch gradients.
+    """
+
+    prefix = "conv2d"
+
+    def __init__(self, filters: int, kernel_size, strides=(1, 1), padding: str = "valid", activation=None,
+                 use_bias: bool = True, input_shape=None, kernel_initializer="glorot_uniform", bias_initializer="zeros",
+                 name=None):
+        super().__init__(name=name, input_shape=input_shape)
+        self.filters = int(filters)
+        self.kernel_size = _pair(kernel_size)
+        self.strides = _pair(strides)
+        self.padding = str(padding).lower()
+        if self.padding not in ("valid", "same"):
+            raise ValueError("padding must be 'valid' or 'same'")
+        if activation not in ACT_CODES:
+            raise ValueError("unsupported activation %r (have: relu, sigmoid, linear)" % (activation,))
+        self.activation = activation
+        self.act = ACT_CODES[activation]
+        self.use_bias = use_bias
+        self.kernel_initializer = kernel_initializer
+        self.bias_initializer = bias_initializer
+        self.kernel = None
+        self.bias = None
+        self.fuse_prev_relu = False      # producing layer's ReLU gradient folded into this layer's col2im
+        self._buf = _Buffers()
+        self._ws = None
+        self._x = self._y = self._cols = None
+
+    def compute_output_shape(self, input_shape):
+        if len(input_shape) != 3:
+            raise ValueError("Conv2D expects per-example shape (H, W, C), got %s" % (input_shape,))
+        H, W, _ = input_shape
+        OH, OW = F.conv_geometry(H, W, *self.kernel_size, self.strides, self.padding)[:2]
+        if OH <= 0 or OW <= 0:
+            raise ValueError("kernel %s does not fit input %s" % (self.kernel_size, input_shape))
+        return (OH, OW, self.filters)
+
+    def build(self, input_shape, store):
+        out = super().build(input_shape, store)
+        kh, kw = self.kernel_size
+        self.kernel = store.create(self.name + "/kernel", (kh, kw, int(input_shape[2]), self.filters),
+                                   self.kernel_initializer)
+        if self.use_bias:
+            self.bias = store.create(self.name + "/bias", (self.filters,), self.bias_initializer)
+        return out
+
+    @property
+    def variables(self):
+        return [v for v in (self.kernel, self.bias) if v is not None]
+
+    def _patches(self, x):
+        kh, kw = self.kernel_size
+        B, H, W, C = x.shape
+        if (kh, kw) == (1, 1) and self.strides == (1, 1):
+            return x.reshape(B * H * W, C)                       # a 1x1 convolution is a plain GEMM over pixels
+        OH, OW, _ = self.output_shape
+        cols = self._buf.get("cols", (B * OH * OW, kh * kw * C), x.device)
+        return F.im2col(x, kh, kw, self.strides, self.padding, out=cols)
+
+    def forward(self, x, training):
+        if x.dim() != 4:
+            raise ValueError("Conv2D expects NHWC input, got shape %s" % (tuple(x.shape),))
+        x = x.contiguous()
+        B = x.shape[0]
+        OH, OW, Fo = self.output_shape
+        cols = self._patches(x)
+        y = self._buf.get("y", (B * OH * OW, Fo), x.device)
+        F.dense_forward(cols, self.kernel.tensor.view(-1, Fo), self.bias.tensor if self.bias is not None else None,
+                        self.act, out=y)
+        self._x, self._cols, self._y = x, cols, y
+        return y.view(B, OH, OW, Fo)
+
+    def backward(self, dy):
+        x, cols, y = self._x, self._cols, self._y
+        M, Fo = y.shape
+        K = cols.shape[1]
+        dy2 = dy.reshape(M, Fo)
+        if self.grad_is_dz or self.act == ACT_NONE:
+            dz = dy2 if dy2.is_contiguous() else dy2.contiguous()
+        else:
+            dz = F.act_grad(dy2.contiguous(), y, self.act, 1.0, out=self._buf.get("dz", y.shape, y.device))
+        if self._ws is None or self._ws[0] != M:
+            need = F.dense_dw_workspace_floats(M, Fo, K) if x.is_cuda else 0
+            if self._ws is None or need > self._ws[1].numel():
+                self._ws = (M, torch.empty(max(need, 1), dtype=torch.float32, device=x.device))
+            else:
+                self._ws = (M, self._ws[1])
+        F.dense_backward_dw(cols, dz, self.kernel.grad.view(-1, Fo), self.bias.grad if self.bias is not None else None,
+                            workspace=self._ws[1])
+        if not self.need_input_grad:
+            return None
+        kh, kw = self.kernel_size
+        if (kh, kw) == (1, 1) and self.strides == (1, 1):
+            dx = self._buf.get("dx", (M, K), x.device)
+            F.dense_backward_dx(dz, self.kernel.tensor.view(-1, Fo), x.reshape(M, K) if self.fuse_prev_relu else None,
+                                ACT_RELU if self.fuse_prev_relu else ACT_NONE, 1.0, out=dx)
+            return dx.view(x.shape)
+        # patch gradients overwrite the patch matrix (wgrad above was its last reader)
+        dcols = F.dense_backward_dx(dz, self.kernel.tensor.view(-1, Fo), out=cols)
+        dx = self._buf.get("dx", x.shape, x.device)
+        return F.col2im(dcols, x.shape, kh, kw, self.strides, self.padding, x if self.fuse_prev_relu else None, out=dx)
+
+    def get_config(self):
+        return {"class": "Conv2D", "name": self.name, "filters": self.filters, "kernel_size": self.kernel_size,
+                "strides": self.strides, "padding": self.padding, "activation": self.activation}
+
+
+class MaxPooling2D(Layer):
+    """Non-overlapping NHWC max pooling (``strides`` = ``pool_size``, VALID), the Keras default."""
+
+    prefix = "max_pooling2d"
+
+    def __init__(self, pool_size=(2, 2), strides=None, padding: str = "valid", name=None):
+        super().__init__(name=name)
+        self.pool_size = _pair(pool_size)
+        if strides is not None and _pair(strides) != self.pool_size:
+            raise NotImplementedError("MaxPooling2D supports strides == pool_size")
+        if str(padding).lower() != "valid":
+            raise NotImplementedError("MaxPooling2D supports padding='valid'")
+        self.fold_relu_grad = False      # the pooled tensor is a ReLU output whose gradient this layer applies
+        self._buf = _Buffers()
+        self._x = self._arg = None
+
+    def compute_output_shape(self, input_shape):
+        if len(input_shape) != 3:
+            raise ValueError("MaxPooling2D expects per-example shape (H, W, C), got %s" % (input_shape,))
+        H, W, C = input_shape
+        OH, OW = H // self.pool_size[0], W // self.pool_size[1]
+        if OH <= 0 or OW <= 0:
+            raise ValueError("pool %s does not fit input %s" % (self.pool_size, input_shape))
+        return (OH, OW, C)
+
+    def forward(self, x, training):
+        x = x.contiguous()
+        B = x.shape[0]
+        shape = (B,) + tuple(self.output_shape)
+        y = self._buf.get("y", shape, x.device)
+        key = ("arg", shape, str(x.device))
+        arg = self._buf._b.get(key)
+        if arg is None:
+            arg = torch.empty(shape, dtype=torch.uint8, device=x.device)
+            self._buf._b[key] = arg
+        F.maxpool_forward(x, self.pool_size, out=y, arg=arg)
+        self._x, self._arg = x, arg
+        return y
+
+    def backward(self, dy):
+        x = self._x
+        dx = self._buf.get("dx", x.shape, x.device)
+        return F.maxpool_backward(dy.contiguous(), self._arg, x.shape, self.pool_size,
+                                  x if self.fold_relu_grad else None, out=dx)
+
+    def get_config(self):
+        return {"class": "MaxPooling2D", "name": self.name, "pool_size": self.pool_size}

@@ -21,7 +21,7 @@ import torch
 from .. import callbacks as cb
 from .. import losses as losses_mod
 from .. import optimizers as optim_mod
-from ..layers import Dense, Dropout, Layer
+from ..layers import Conv2D, Dense, Dropout, Layer, MaxPooling2D
 from ..ops import functional as F
 from ..ops._native import ACT_NONE, ACT_RELU, ACT_SIGMOID
 from ..variables import VariableStore
@@ -126,6 +126,12 @@ class Sequential:
                 b.fuse_prev_grad = True
                 b.prev_act = a.act
                 b.prev_scale = 1.0 / a.fused_keep
+                a.grad_is_dz = True
+            elif isinstance(a, Conv2D) and a.act == ACT_RELU and isinstance(b, MaxPooling2D):
+                b.fold_relu_grad = True          # pooling backward also applies the conv's ReLU gradient
+                a.grad_is_dz = True
+            elif isinstance(a, Conv2D) and a.act == ACT_RELU and isinstance(b, Conv2D):
+                b.fuse_prev_relu = True          # col2im (or the 1x1 dgrad epilogue) applies it
                 a.grad_is_dz = True
         if eff:
             eff[0].need_input_grad = False

@@ -67,6 +67,10 @@ def kernels():
         "dtf_scale": [c_p, c_ll, c_f, c_p],
         "dtf_activation": [c_p, c_p, c_ll, c_i, c_p],
         "dtf_softmax_rows": [c_p, c_p, c_i, c_i, c_p],
+        "dtf_im2col": [c_p, c_p] + [c_i] * 12 + [c_p],
+        "dtf_col2im": [c_p, c_p, c_p] + [c_i] * 12 + [c_p],
+        "dtf_maxpool_fwd": [c_p, c_p, c_p] + [c_i] * 6 + [c_p],
+        "dtf_maxpool_bwd": [c_p, c_p, c_p, c_p] + [c_i] * 6 + [c_p],
         "dtf_mlp3_fused_supported": [c_i, c_i, c_i, c_i, c_i],
         "dtf_mlp3_fused_train": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
                                  c_f, c_f, c_u32, c_u32, c_f, c_f, c_f, c_f, c_p, c_p, c_p, c_p],

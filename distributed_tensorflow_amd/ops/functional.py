@@ -410,3 +410,104 @@ def mlp3_fused_train(x, y, params, slot_m, slot_v, offsets, dims, batch, nsteps,
         int(bool(want_cat)), float(keep1), float(keep2), int(seed1) & _M32, int(seed2) & _M32, float(lr), float(beta1),
         float(beta2), float(eps), nv.ptr(step), nv.ptr(beta_powers), nv.ptr(stats), nv.stream_ptr())
     nv.check(rc, "dtf_mlp3_fused_train")
+
+
+# ----------------------------------------------------------------------------- convolution support (NHWC)
+def conv_geometry(H, W, KH, KW, strides=(1, 1), padding="valid"):
+    """Output size and top/left zero padding, TensorFlow rules ('same': out = ceil(in / stride), extra padding goes
+    to the bottom/right)."""
+    sh, sw = strides
+    if padding == "same":
+        OH, OW = -(-H // sh), -(-W // sw)
+        ph = max((OH - 1) * sh + KH - H, 0)
+        pw = max((OW - 1) * sw + KW - W, 0)
+        return OH, OW, ph // 2, pw // 2, ph - ph // 2, pw - pw // 2
+    if padding != "valid":
+        raise ValueError("padding must be 'valid' or 'same'")
+    return (H - KH) // sh + 1, (W - KW) // sw + 1, 0, 0, 0, 0
+
+
+def im2col(x, KH, KW, strides=(1, 1), padding="valid", out=None):
+    """Patch matrix ``[B*OH*OW, KH*KW*C]`` of an NHWC tensor, column order (kh, kw, c) = a TF filter flattened."""
+    B, H, W, C = x.shape
+    OH, OW, pt, pl, pb, pr = conv_geometry(H, W, KH, KW, strides, padding)
+    M, K = B * OH * OW, KH * KW * C
+    if out is None:
+        out = torch.empty((M, K), dtype=torch.float32, device=x.device)
+    if x.is_cuda:
+        nv.require_f32_contig(x, out)
+        rc = nv.kernels().dtf_im2col(nv.ptr(x), nv.ptr(out), B, H, W, C, KH, KW, OH, OW, pt, pl, strides[0], strides[1],
+                                     nv.stream_ptr())
+        nv.check(rc, "dtf_im2col")
+        return out
+    xp = torch.nn.functional.pad(x.permute(0, 3, 1, 2), (pl, pr, pt, pb))
+    u = torch.nn.functional.unfold(xp, (KH, KW), stride=strides)                    # [B, C*KH*KW, L], (c, kh, kw) order
+    u = u.view(B, C, KH, KW, OH * OW).permute(0, 4, 2, 3, 1).reshape(M, K)
+    out.copy_(u)
+    return out
+
+
+def col2im(dcols, x_shape, KH, KW, strides=(1, 1), padding="valid", yprev=None, out=None):
+    """Adjoint of ``im2col``: scatter-add patch gradients back to the NHWC image; ``yprev`` (the producing layer's ReLU
+    output, same shape as the image) folds that layer's activation gradient in."""
+    B, H, W, C = x_shape
+    OH, OW, pt, pl, pb, pr = conv_geometry(H, W, KH, KW, strides, padding)
+    if out is None:
+        out = torch.empty(tuple(x_shape), dtype=torch.float32, device=dcols.device)
+    if dcols.is_cuda:
+        nv.require_f32_contig(dcols, out, yprev)
+        rc = nv.kernels().dtf_col2im(nv.ptr(dcols), nv.ptr(out), nv.ptr(yprev), B, H, W, C, KH, KW, OH, OW, pt, pl,
+                                     strides[0], strides[1], nv.stream_ptr())
+        nv.check(rc, "dtf_col2im")
+        return out
+    u = dcols.view(B, OH * OW, KH, KW, C).permute(0, 4, 2, 3, 1).reshape(B, C * KH * KW, OH * OW)
+    f = torch.nn.functional.fold(u, (H + pt + pb, W + pl + pr), (KH, KW), stride=strides)
+    dx = f[:, :, pt:pt + H, pl:pl + W].permute(0, 2, 3, 1)
+    if yprev is not None:
+        dx = dx * (yprev > 0).to(dx.dtype)
+    out.copy_(dx)
+    return out
+
+
+def maxpool_forward(x, pool=(2, 2), out=None, arg=None):
+    """Non-overlapping max pooling (stride = window, VALID) of an NHWC tensor; returns ``(y, argmax uint8)``."""
+    B, H, W, C = x.shape
+    PH, PW = pool
+    OH, OW = H // PH, W // PW
+    if out is None:
+        out = torch.empty((B, OH, OW, C), dtype=torch.float32, device=x.device)
+    if arg is None:
+        arg = torch.empty((B, OH, OW, C), dtype=torch.uint8, device=x.device)
+    if x.is_cuda:
+        nv.require_f32_contig(x, out)
+        rc = nv.kernels().dtf_maxpool_fwd(nv.ptr(x), nv.ptr(out), nv.ptr(arg), B, H, W, C, PH, PW, nv.stream_ptr())
+        nv.check(rc, "dtf_maxpool_fwd")
+        return out, arg
+    win = x[:, :OH * PH, :OW * PW, :].reshape(B, OH, PH, OW, PW, C).permute(0, 1, 3, 5, 2, 4).reshape(B, OH, OW, C, PH * PW)
+    v, i = win.max(dim=-1)
+    out.copy_(v)
+    arg.copy_(i.to(torch.uint8))
+    return out, arg
+
+
+def maxpool_backward(dy, arg, x_shape, pool=(2, 2), x_relu=None, out=None):
+    """Route ``dy`` to each window's arg-max position; ``x_relu`` (the pooled tensor, a ReLU output) folds the ReLU
+    gradient in."""
+    B, H, W, C = x_shape
+    PH, PW = pool
+    OH, OW = H // PH, W // PW
+    if out is None:
+        out = torch.empty(tuple(x_shape), dtype=torch.float32, device=dy.device)
+    if dy.is_cuda:
+        nv.require_f32_contig(dy, out, x_relu)
+        rc = nv.kernels().dtf_maxpool_bwd(nv.ptr(dy), nv.ptr(arg), nv.ptr(x_relu), nv.ptr(out), B, H, W, C, PH, PW,
+                                          nv.stream_ptr())
+        nv.check(rc, "dtf_maxpool_bwd")
+        return out
+    onehot = torch.nn.functional.one_hot(arg.to(torch.int64), PH * PW).to(dy.dtype) * dy.unsqueeze(-1)   # [B,OH,OW,C,P]
+    g = onehot.view(B, OH, OW, C, PH, PW).permute(0, 1, 4, 2, 5, 3).reshape(B, OH * PH, OW * PW, C)
+    out.zero_()
+    out[:, :OH * PH, :OW * PW, :] = g
+    if x_relu is not None:
+        out.mul_((x_relu > 0).to(out.dtype))
+    return out
