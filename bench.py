@@ -8,9 +8,11 @@ Adam, softmax cross-entropy) in fp32 on N MI355X GPUs of one node.
         --master-port 29500 bench.py --gpus 8 --steps 50 --warmup 10
 
 Every timed step is a complete training step on fresh device-resident synthetic data:
-forward, loss, backward, gradient reduce-scatter, sharded Adam apply, parameter
-all-gather, global_step increment.  Weak scaling: the per-GPU batch is fixed.
-Rank 0 prints ONE JSON line.
+forward, loss, backward, gradient exchange, Adam apply, global_step increment.  The
+gradient exchange is one RCCL all-reduce of the flat gradient plus a replicated apply when
+the model is small (latency-bound; the default model is), and bucketed reduce-scatter ->
+sharded Adam -> all-gather overlapped with backward when it is large (--model wide_mlp).
+Weak scaling: the per-GPU batch is fixed.  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
@@ -42,6 +44,8 @@ def parse_args():
     ap.add_argument("--bucket-mb", type=float, default=64.0)
     ap.add_argument("--width", type=int, default=16384, help="wide_mlp hidden width")
     ap.add_argument("--depth", type=int, default=5, help="wide_mlp hidden depth")
+    ap.add_argument("--single-rank-collectives", type=int, default=0,
+                    help="testing aid: run the multi-GPU code path (RCCL calls included) on a 1-rank process group")
     ap.add_argument("--eval", type=int, default=0, help="also train for this many extra steps and report test accuracy")
     return ap.parse_args()
 
@@ -70,8 +74,15 @@ def main():
     _native.kernels()  # fail loudly if the HIP library is missing
 
     strategy = None
-    if world > 1:
-        init_process_group("nccl", device=dev)
+    multi = world > 1 or bool(args.single_rank_collectives)
+    if multi:
+        if world == 1:
+            os.environ["DTF_FORCE_COLLECTIVES"] = "1"
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+            init_process_group("nccl", rank=0, world_size=1, device=dev)
+        else:
+            init_process_group("nccl", device=dev)
         strategy = SyncReplicasStrategy(Communicator(), bucket_bytes=int(args.bucket_mb * (1 << 20)))
 
     B = args.batch_per_gpu or DEFAULT_BATCH[args.model]
@@ -97,7 +108,7 @@ def main():
 
     pool = max(1, args.pool)
     # small-batch reference network on one GPU: the whole step (and runs of consecutive steps) is one launch
-    plan = model.fused_step_plan(B) if (args.fused != 0 and world == 1) else None
+    plan = model.fused_step_plan(B) if (args.fused != 0 and not multi) else None
     if args.fused == 1 and plan is None:
         raise SystemExit("--fused 1: no fused step kernel for this model / batch / world size")
     if plan is not None:
@@ -105,10 +116,16 @@ def main():
     x_all, y_all = make(B * pool, 1000 + rank)
     batches = [(x_all[i * B:(i + 1) * B], y_all[i * B:(i + 1) * B]) for i in range(pool)]
 
-    use_graph = plan is None and ((args.graph == 1) or (args.graph == -1 and world == 1))
-    graphs = None
-    if use_graph:
+    use_graph = plan is None and ((args.graph == 1) or (args.graph == -1 and not multi))
+    graphs = grad_graphs = None
+    if use_graph and not multi:
         graphs = [model._graphed_steps(bx, by, B, 1) for bx, by in batches]
+    elif plan is None and args.graph == 1 and multi and getattr(strategy, "replicated", False):
+        # small per-GPU batches (host-bound eager launches): forward+loss+backward replays from a hipGraph, the
+        # gradient all-reduce and the replicated apply follow eagerly (RCCL stays outside the graph).  At the
+        # default batch the GPU is the bottleneck and eager launches measured 4 % faster, so this is opt-in.
+        grad_graphs = [model.graphed_gradients(bx, by) for bx, by in batches]
+        use_graph = True
 
     def run(first, count):
         """Training steps first .. first+count-1; step i consumes batch i % pool."""
@@ -123,6 +140,10 @@ def main():
         for i in range(first, first + count):
             if graphs is not None:
                 graphs[i % pool].replay()
+            elif grad_graphs is not None:
+                grad_graphs[i % pool].replay()
+                model.strategy.apply_gradients(model)
+                model._host_step += 1
             else:
                 bx, by = batches[i % pool]
                 model.train_step(bx, by)
@@ -131,7 +152,7 @@ def main():
         run(i, 1)
 
     def fence():
-        if world > 1:
+        if multi:
             dist.barrier(device_ids=[dev.index])
         torch.cuda.synchronize()
 
@@ -176,7 +197,7 @@ def main():
                        "train_loss": logs.get("loss"), "train_acc": logs.get("acc"), "test_acc": test_acc},
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier(device_ids=[dev.index])
         dist.destroy_process_group()
 

@@ -305,6 +305,31 @@ class Sequential:
         self._graphs[key] = g
         return g
 
+    def graphed_gradients(self, x_buf: torch.Tensor, y_buf: torch.Tensor):
+        """hipGraph of forward + loss + backward on a fixed batch buffer (no variable update).  A replica whose
+        gradient exchange runs outside the graph replays this, then calls ``strategy.apply_gradients`` - two host
+        calls per step instead of one launch per kernel.  Not usable while a strategy overlaps collectives with
+        backward through the per-layer hook."""
+        if self._after_layer_backward is not None:
+            raise RuntimeError("gradient graphs cannot contain the strategy's per-layer collectives")
+        key = ("grad", x_buf.data_ptr(), y_buf.data_ptr(), tuple(x_buf.shape))
+        g = self._graphs.get(key)
+        if g is not None:
+            return g
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        saved_stats = self.stats.clone()
+        with torch.cuda.stream(side):
+            self.compute_gradients(x_buf, y_buf)       # warm-up: every lazily allocated buffer exists afterwards
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.stats.copy_(saved_stats)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.compute_gradients(x_buf, y_buf)
+        self._graphs[key] = g
+        return g
+
     # ------------------------------------------------------------------ whole-step kernel
     def fused_step_plan(self, batch_size: int):
         """Arguments for the one-launch training step (``csrc/kernels/mlp_fused.hip``) when this model is the

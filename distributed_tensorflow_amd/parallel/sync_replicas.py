@@ -18,6 +18,11 @@ backward GEMMs.  Collectives are large by default (64 MiB buckets): ring collect
 point-to-point xGMI are per-link bound and launch latency is tens of microseconds, so
 fewer, larger messages win; a model smaller than one bucket is a single collective pair.
 
+A model whose whole gradient is a few megabytes (the reference network is 116 KB) is latency-bound
+instead: there the strategy runs "replicated" - ONE all-reduce of the flat gradient, then every rank
+applies the full update to its own copy - one collective launch per step, nothing to gather, and
+forward+backward can replay from a hipGraph because no collective sits inside it.
+
 In a fully synchronous collective there is no stale gradient to drop (TF's
 ``local_step < global_step`` test): every rank contributes exactly one gradient per step.
 """
@@ -45,13 +50,18 @@ class _Bucket:
 
 class SyncReplicasStrategy:
     def __init__(self, comm: Optional[Communicator] = None, bucket_bytes: int = 64 << 20, overlap: bool = True,
-                 average: bool = True):
+                 average: bool = True, allreduce_below_bytes: int = 8 << 20):
         self.comm = comm if comm is not None else Communicator()
         self.world_size = self.comm.world_size
         self.rank = self.comm.rank
         self.bucket_bytes = int(bucket_bytes)
         self.overlap = overlap
         self.average = average
+        # Models whose whole flat gradient is below this size are latency-bound: ONE all-reduce of the flat gradient
+        # and a replicated apply (every rank updates every variable) beats a reduce-scatter / all-gather pair with a
+        # sharded apply in between - one collective launch per step instead of two, nothing to gather afterwards.
+        self.allreduce_below_bytes = int(allreduce_below_bytes)
+        self.replicated = False
         self.buckets: List[_Bucket] = []
         self._layer_bucket: Dict[int, _Bucket] = {}
         # exercise the real collectives even with one rank (GPU-box test of the RCCL path)
@@ -76,6 +86,13 @@ class SyncReplicasStrategy:
         self.comm.broadcast(store.global_step, 0)
         for s in store.slots.values():
             self.comm.broadcast(s, 0)
+        self._device = store.device
+        self.replicated = store.flat_len * 4 <= self.allreduce_below_bytes
+        if self.replicated:
+            self.buckets = []
+            self._layer_bucket = {}
+            model._after_layer_backward = None
+            return
         self._build_buckets(model)
         model._after_layer_backward = self._on_layer_backward if self.overlap else None
 
@@ -133,9 +150,25 @@ class SyncReplicasStrategy:
         if b.pending == 0:
             self._launch(b, model.store)
 
+    def _apply_replicated(self, model, scale):
+        store = model.store
+        c = self.comm
+        if self.world_size > 1 or self.force:
+            if c.world_size == 1:      # forced single-rank collective (GPU-box test of the RCCL call path)
+                import torch.distributed as dist
+                work = dist.all_reduce(store.flat_grad, group=c.group, async_op=True) if c.backend == "nccl" else None
+            else:
+                work = c.all_reduce_sum(store.flat_grad, async_op=(c.backend == "nccl"))
+            if work is not None and hasattr(work, "wait"):
+                work.wait()            # stream-level wait under RCCL: the host does not block
+        model.optimizer.apply(store, grad_scale=scale)
+        model.optimizer.finish_step(store)
+
     def apply_gradients(self, model):
         store = model.store
         scale = 1.0 / self.world_size if self.average else 1.0
+        if self.replicated:
+            return self._apply_replicated(model, scale)
         gathers = []
         for b in self.buckets:
             if b.pending > 0:  # not launched from the backward hook
@@ -184,7 +217,7 @@ class SyncReplicasStrategy:
     def gather_slots(self, model):
         """Collective: make every replica's optimizer-slot buffers complete (each replica only updates the
         slots of the shards it owns), so that the chief can write a full checkpoint."""
-        if self.world_size == 1:
+        if self.world_size == 1 or self.replicated:      # replicated apply keeps every slot complete everywhere
             return
         store = model.store
         for name in sorted(store.slots):
@@ -196,8 +229,7 @@ class SyncReplicasStrategy:
         """The chief's boolean decision, on every replica (one tiny broadcast)."""
         if self.world_size == 1:
             return bool(flag)
-        t = torch.tensor([1 if flag else 0], dtype=torch.int64, device=self.buckets[0].shard.device if self.buckets
-                         else "cpu")
+        t = torch.tensor([1 if flag else 0], dtype=torch.int64, device=getattr(self, "_device", "cpu"))
         self.comm.broadcast(t, 0)
         return bool(t.item())
 

@@ -114,20 +114,33 @@ dev = torch.device("cuda", 0)
 init_process_group("nccl", rank=0, world_size=1, master_addr="127.0.0.1", master_port=%d, device=dev)
 x, y = mnist_like(4096, seed=0, device=dev)
 outs = []
-for strat in (None, SyncReplicasStrategy(Communicator(), bucket_bytes=1 << 16)):
+for mode in ("local", "bucketed", "replicated", "replicated+graph"):
+    strat = None
+    if mode == "bucketed":
+        strat = SyncReplicasStrategy(Communicator(), bucket_bytes=1 << 16, allreduce_below_bytes=0)
+    elif mode.startswith("replicated"):
+        strat = SyncReplicasStrategy(Communicator())
     m = mnist_mlp()
     for i, l in enumerate(m.layers):
         if hasattr(l, "seed"): l.seed = 100 + i
     m.compile(loss="sparse_categorical_crossentropy", optimizer="adam", metrics=["accuracy"], strategy=strat, device=dev, seed=0)
     for i in range(8):
-        m.train_step(x[i*512:(i+1)*512], y[i*512:(i+1)*512])
+        xb, yb = x[i*512:(i+1)*512], y[i*512:(i+1)*512]
+        if mode == "replicated+graph":
+            m.graphed_gradients(xb, yb).replay()      # forward+loss+backward from a hipGraph, RCCL call eager
+            m.strategy.apply_gradients(m)
+        else:
+            m.train_step(xb, yb)
     torch.cuda.synchronize()
     outs.append([v.tensor.clone() for v in m.store.trainable] + [m.global_step])
-    if strat is not None:
-        assert len(strat.buckets) > 1
-for a, b in zip(outs[0][:-1], outs[1][:-1]):
-    torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-7)
-assert outs[0][-1] == outs[1][-1] == 8
+    if mode == "bucketed":
+        assert len(strat.buckets) > 1 and not strat.replicated
+    if mode.startswith("replicated"):
+        assert strat.replicated and not strat.buckets
+for other in outs[1:]:
+    for a, b in zip(outs[0][:-1], other[:-1]):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-7)
+    assert outs[0][-1] == other[-1] == 8
 import torch.distributed as dist
 dist.destroy_process_group()
 print("RCCL_OK")

@@ -18,7 +18,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, bucket_bytes, out_q):
+def _worker(rank, world, port, bucket_bytes, allreduce_below, out_q):
     sys.path.insert(0, ROOT)
     torch.set_num_threads(1)
     from distributed_tensorflow_amd.data import mnist_like
@@ -28,7 +28,7 @@ def _worker(rank, world, port, bucket_bytes, out_q):
     init_process_group("gloo", rank=rank, world_size=world, master_addr="127.0.0.1", master_port=port)
     m = Sequential([Dense(32, input_dim=784, activation="relu"), Dense(32, activation="relu"),
                     Dense(10, activation="softmax")])
-    strat = SyncReplicasStrategy(Communicator(), bucket_bytes=bucket_bytes)
+    strat = SyncReplicasStrategy(Communicator(), bucket_bytes=bucket_bytes, allreduce_below_bytes=allreduce_below)
     m.compile(loss="sparse_categorical_crossentropy", optimizer="adam", metrics=["accuracy"], strategy=strat,
               device="cpu", seed=100 + rank)  # different seeds: rank 0's init must win
     x, y = mnist_like(64 * world, seed=3)
@@ -36,19 +36,20 @@ def _worker(rank, world, port, bucket_bytes, out_q):
     for _ in range(5):
         m.train_step(xs, ys)
     logs = m.read_stats()
-    out_q.put((rank, m.store.flat.clone(), m.global_step, logs, len(strat.buckets)))
+    out_q.put((rank, m.store.flat.clone(), m.global_step, logs, len(strat.buckets), strat.replicated))
     import torch.distributed as dist
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("bucket_bytes", [64 << 20, 4096])
-def test_sync_replicas_matches_single_process(bucket_bytes):
+@pytest.mark.parametrize("bucket_bytes,allreduce_below", [(64 << 20, 0), (4096, 0), (64 << 20, 8 << 20)],
+                         ids=["one_bucket", "many_buckets", "replicated_allreduce"])
+def test_sync_replicas_matches_single_process(bucket_bytes, allreduce_below):
     world = 2
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, bucket_bytes, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, bucket_bytes, allreduce_below, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
@@ -60,6 +61,7 @@ def test_sync_replicas_matches_single_process(bucket_bytes):
     assert res[0][2] == 5 and res[1][2] == 5
     if bucket_bytes == 4096:
         assert res[0][4] > 1
+    assert res[0][5] == (allreduce_below > 0) and (not res[0][5] or res[0][4] == 0)
 
     # single-process reference on the union batch with rank 0's initial values
     sys.path.insert(0, ROOT)
