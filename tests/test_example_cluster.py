@@ -85,6 +85,8 @@ def test_one_ps_two_workers(tmp_path, mode):
     assert names["dense_1/kernel"] == (64, 128) and names["global_step"] == ()
     assert "dense_3/kernel/Adam_1" in names
     with BundleReader(ck) as r:
-        assert int(r.get_tensor("global_step").item()) == step
+        # asynchronous mode: the other worker's push may land between the chief reading global_step for the file name
+        # and the owner snapshotting its shard (TensorFlow's SaveV2 on a live parameter server has the same window)
+        assert step <= int(r.get_tensor("global_step").item()) <= step + 1
         assert r.get_tensor("dense_1/kernel").abs().sum() > 0
     assert glob.glob(os.path.join(str(tmp_path), "events.out.tfevents.*"))
