@@ -1,0 +1,79 @@
+// Building blocks for kernels that keep both GEMM operands in LDS (the one-launch step kernel and the fused
+// network-tail kernel): register-staged global->LDS block copies and a 32x32 MFMA tile product on LDS operands.
+#pragma once
+#include "common.h"
+
+typedef unsigned int dtf_u32x4 __attribute__((vector_size(16)));
+
+// A [ROWS x COLS] block of a row-major matrix is ROWS*COLS/4 16-byte vectors; thread `tid` of NT owns vectors tid,
+// tid+NT, ...  Loads go through a buffer resource of `bytes` bytes: reads past it return zero, which pads a ragged
+// batch without a branch.  issue() only requests the data; commit() writes the LDS image [ROWS][COLS+4] - so a
+// block requested before a compute phase lands under it.
+template <int NT, int ROWS, int COLS>
+struct LdsStage {
+    static constexpr int NV = ROWS * COLS / 4 / NT;
+    static_assert(NV * NT * 4 == ROWS * COLS, "block must split evenly over the workgroup");
+    f32x4 v[NV];
+
+    // `ld`: row stride of the source in floats; SC1: L2-served load (for data another launch phase rewrote)
+    template <bool SC1>
+    __device__ __forceinline__ void issue(const float* base, unsigned bytes, int ld, int tid) {
+        __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)bytes, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + NT * i;
+            const int row = idx / (COLS / 4), c = (idx % (COLS / 4)) * 4;
+            // whole-vector bit_cast only: indexing the builtin's result element-wise makes hipcc (ROCm 7.2) emit
+            // a single-dword load
+            const dtf_u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(r, (row * ld + c) * 4, 0, SC1 ? 16 : 0);
+            v[i] = __builtin_bit_cast(f32x4, raw);
+        }
+    }
+    __device__ __forceinline__ void commit(float* dst, int tid) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + NT * i;
+            const int row = idx / (COLS / 4), c = (idx % (COLS / 4)) * 4;
+            *reinterpret_cast<f32x4*>(dst + row * (COLS + 4) + c) = v[i];
+        }
+    }
+};
+
+// One 32x32 output tile: acc += sum_k A(m,k) B(k,n), both operands in LDS, on v_mfma_f32_32x32x2_f32.
+//   A_KC: A[m][k] row-major (k contiguous)   else A[k][m]
+//   B_KC: B[n][k] row-major (k contiguous)   else B[k][n]
+// Lane (li = lane & 31, h = lane >> 5) feeds row/column li; within a group of 8 k-values half h takes k = 4h..4h+3,
+// so a k-contiguous operand is one 16-byte LDS read per group (row strides with stride/4 odd are conflict-free).
+template <bool A_KC, bool B_KC, int K>
+__device__ __forceinline__ void lds_tile_mma(f32x16& acc, const float* A, int lda, int m0, const float* B, int ldb, int n0,
+                                             int lane) {
+    const int li = lane & 31, h = lane >> 5;
+    const float* pa = A_KC ? A + (m0 + li) * lda + 4 * h : A + (4 * h) * lda + m0 + li;
+    const float* pb = B_KC ? B + (n0 + li) * ldb + 4 * h : B + (4 * h) * ldb + n0 + li;
+#pragma unroll 4
+    for (int kk = 0; kk < K; kk += 8) {
+        f32x4 a, b;
+        if (A_KC) {
+            a = *reinterpret_cast<const f32x4*>(pa + kk);
+        } else {
+            const float* q = pa + kk * lda;
+            a[0] = q[0]; a[1] = q[lda]; a[2] = q[2 * lda]; a[3] = q[3 * lda];
+        }
+        if (B_KC) {
+            b = *reinterpret_cast<const f32x4*>(pb + kk);
+        } else {
+            const float* q = pb + kk * ldb;
+            b[0] = q[0]; b[1] = q[ldb]; b[2] = q[2 * ldb]; b[3] = q[3 * ldb];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], acc, 0, 0, 0);
+    }
+}
+
+__device__ __forceinline__ void lds_zero(f32x16& a) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = 0.f;
+}
+
+// row of accumulator register r inside a 32x32 tile for lane half h (column = lane & 31)
+__device__ __forceinline__ int lds_tile_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }

@@ -1,0 +1,334 @@
+// Fused "network tail": everything after the first (wide-input) layer of an MLP classifier in one kernel.
+//
+//   h1 [M,128] (first layer's output, after its ReLU and dropout)
+//     -> h2 = dropout(relu(h1 W2 + b2))            [M,128]
+//     -> z  = h2 W3 + b3                           [M,C], C <= 16
+//     -> softmax cross-entropy vs. sparse labels    loss / accuracy statistics, dz3
+//     -> dW3, db3, dz2 = (dz3 W3^T) * relu'(h2) * dropout
+//     -> dW2, db2, dz1 = (dz2 W2^T) * relu'(h1) * dropout
+//
+// With 128-wide hidden layers each of these GEMMs is a few microseconds of MFMA work; as separate kernels
+// (three forward, loss, two dgrad, two wgrad, two slab reductions) their launch / fill / drain costs dominate and
+// h2, z, dz3, dz2 make round trips through HBM.  Here a workgroup owns 64-row slabs of the batch: a slab's
+// activations never leave LDS, W2 and W3 are loaded into LDS once per workgroup, the weight gradients
+// accumulate in registers across the workgroup's slabs and leave as one partial slab per workgroup, and the only
+// per-row HBM traffic is h1 in and dz1 out.  Dropout masks are the counter-based function of
+// (seed, global_step, row, column) the layer-wise kernels use, so both paths draw identical masks.
+#include "lds_mma.h"
+
+namespace {
+
+constexpr int NT = 512;                 // 8 waves, two per SIMD
+constexpr int BM = 64;                  // rows per slab
+constexpr int H = 128;                  // hidden width of both tail layers
+constexpr int CP = 16;                  // classes padded
+constexpr int LH = H + 4, LC = CP + 4;  // LDS row strides (floats), stride/4 odd
+constexpr int SW3_FLOATS = H * LC + 32; // + slack: 32-lane reads of a 20-float row run past the last row
+constexpr int LDS_FLOATS = 2 * BM * LH + H * LH + SW3_FLOATS + 2 * BM * LC + 32 /*slack*/ + H + CP + 32;
+static_assert(LDS_FLOATS * 4 <= 160 * 1024, "slab + weights must fit one CU's LDS");
+
+struct TailArgs {
+    const float* H1;
+    const float* W2;
+    const float* b2;
+    const float* W3;
+    const float* b3;
+    const long long* labels;
+    float* dZ1;
+    float* slabs;            // [gridDim.x][slab_stride]: dW2 | db2 | dW3 | db3
+    long long slab_stride;
+    int M, C;
+    float keep2;
+    uint32_t seed2;
+    const long long* step_ptr;
+    float scale1;            // 1 / keep-probability of the first layer's dropout
+    float grad_scale;        // 1 / global batch
+    float* stats;            // [>=3]: loss sum, correct count, example count
+};
+
+__global__ __launch_bounds__(NT, 1) void mlp_tail_kernel(const TailArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* sH1 = lds;
+    float* sH2 = sH1 + BM * LH;
+    float* sW2 = sH2 + BM * LH;
+    float* sW3 = sW2 + H * LH;
+    float* sPa = sW3 + SW3_FLOATS;       // logits k-half 0, then dz3
+    float* sPb = sPa + BM * LC;          // logits k-half 1
+    float* sB2 = sPb + BM * LC + 32;
+    float* sB3 = sB2 + H;
+    float* sRed = sB3 + CP;
+
+    const int tid0 = threadIdx.x;
+    int tid = tid0;
+    const int C = p.C;
+    const bool drop2 = p.keep2 < 1.0f;
+    const float scale2 = drop2 ? 1.0f / p.keep2 : 1.0f;
+    const uint32_t key2 = dtf_dropout_key(p.seed2, p.step_ptr);
+    const int nslabs = (p.M + BM - 1) / BM;
+
+    // ---- once per workgroup: weights and biases into LDS
+    {
+        LdsStage<NT, H, H> w2;
+        w2.template issue<false>(p.W2, (unsigned)(H * H * 4), H, tid);
+        for (int e = tid; e < SW3_FLOATS; e += NT) {
+            const int k = e / LC, c = e - k * LC;
+            sW3[e] = (k < H && c < C) ? p.W3[k * C + c] : 0.f;
+        }
+        if (tid < H) sB2[tid] = p.b2[tid];
+        if (tid < CP) sB3[tid] = tid < C ? p.b3[tid] : 0.f;
+        for (int e = tid; e < 2 * BM * LC + 32; e += NT) sPa[e] = 0.f;
+        w2.commit(sW2, tid);
+    }
+    LdsStage<NT, BM, H> ph;
+    int slab = blockIdx.x;
+    if (slab < nslabs) {
+        const int rows = min(BM, p.M - slab * BM);
+        ph.template issue<false>(p.H1 + (long long)slab * BM * H, (unsigned)rows * H * 4, H, tid);
+    }
+    f32x16 g2[2], g3;
+    lds_zero(g2[0]); lds_zero(g2[1]); lds_zero(g3);
+    float db2r = 0.f, db3r = 0.f, loss = 0.f, correct = 0.f, count = 0.f;
+
+    for (; slab < nslabs; slab += gridDim.x) {
+        // The thread index is made opaque once per slab: the addresses below are loop-invariant and hoisting them
+        // all would cost more registers than recomputing them.
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int li = lane & 31, h = lane >> 5;
+        const int tm = wave >> 2, tn = wave & 3;
+        const int col = tn * 32 + li;
+        const int row0 = slab * BM;
+        const int rows = min(BM, p.M - row0);
+
+        ph.commit(sH1, tid);
+        __syncthreads();
+        if (slab + (int)gridDim.x < nslabs) {
+            const int nslab = slab + gridDim.x;
+            const int nrows = min(BM, p.M - nslab * BM);
+            ph.template issue<false>(p.H1 + (long long)nslab * BM * H, (unsigned)nrows * H * 4, H, tid);
+        }
+        // ---- h2 = dropout(relu(h1 W2 + b2)): one 32x32 tile per wave
+        {
+            f32x16 acc; lds_zero(acc);
+            lds_tile_mma<true, false, H>(acc, sH1, LH, tm * 32, sW2, LH, tn * 32, lane);
+            const float bv = sB2[col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = tm * 32 + lds_tile_row(r, h);
+                float v = fmaxf(acc[r] + bv, 0.f);
+                if (drop2)
+                    v = (dtf_uniform(key2, (unsigned long long)(row0 + row) * (unsigned)H + col) < p.keep2) ? v * scale2 : 0.f;
+                sH2[row * LH + col] = v;
+            }
+        }
+        __syncthreads();
+        // ---- logits: two row tiles x two k-halves on waves 0..3; the halves meet in the softmax pass (fixed order)
+        if (wave < 4) {
+            const int rt = wave & 1, kh = wave >> 1;
+            f32x16 acc; lds_zero(acc);
+            lds_tile_mma<true, false, 64>(acc, sH2 + kh * 64, LH, rt * 32, sW3 + kh * 64 * LC, LC, 0, lane);
+            float* dst = kh ? sPb : sPa;
+            if (li < CP) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dst[(rt * 32 + lds_tile_row(r, h)) * LC + li] = acc[r];
+            }
+        }
+        __syncthreads();
+        // ---- softmax cross-entropy, one thread per row; dz3 replaces the logits (zero in rows past the batch and
+        //      in the padded classes)
+        if (tid < BM) {
+            float* z = sPa + tid * LC;
+            if (tid < rows) {
+                const float* zb = sPb + tid * LC;
+                float v[CP];
+                float mx = -INFINITY;
+                int arg = 0;
+#pragma unroll
+                for (int c = 0; c < CP; ++c) {
+                    v[c] = z[c] + zb[c] + sB3[c];
+                    if (c < C && v[c] > mx) { mx = v[c]; arg = c; }
+                }
+                float se = 0.f;
+#pragma unroll
+                for (int c = 0; c < CP; ++c) {
+                    v[c] = c < C ? __expf(v[c] - mx) : 0.f;
+                    se += v[c];
+                }
+                const int label = (int)p.labels[row0 + tid];
+                const float inv = 1.0f / se;
+                float zl = 0.f;
+#pragma unroll
+                for (int c = 0; c < CP; ++c) {
+                    if (c == label) zl = v[c];
+                    z[c] = c < C ? (v[c] * inv - (c == label ? 1.f : 0.f)) * p.grad_scale : 0.f;
+                }
+                loss += -__logf(zl * inv);
+                correct += (arg == label) ? 1.f : 0.f;
+                count += 1.f;
+            } else {
+#pragma unroll
+                for (int c = 0; c < CP; ++c) z[c] = 0.f;
+            }
+        }
+        __syncthreads();
+        // ---- dW3 += h2^T dz3 (waves 0..3, input-unit block = wave); dz2 products (all waves), both read h2 / dz3
+        if (wave < 4) lds_tile_mma<false, false, BM>(g3, sH2, LH, wave * 32, sPa, LC, 0, lane);
+        f32x16 az; lds_zero(az);
+        lds_tile_mma<true, true, CP>(az, sPa, LC, tm * 32, sW3, LC, tn * 32, lane);
+        if (tid < CP) {
+            float s = 0.f;
+            for (int r = 0; r < BM; ++r) s += sPa[r * LC + tid];
+            db3r += s;
+        }
+        __syncthreads();
+        // ---- dz2 = (dz3 W3^T) * (h2 > 0) / keep2 in place of h2
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = tm * 32 + lds_tile_row(r, h);
+            const float y = sH2[row * LH + col];
+            sH2[row * LH + col] = (y > 0.f) ? az[r] * scale2 : 0.f;
+        }
+        __syncthreads();
+        // ---- dW2 += h1^T dz2: tiles t = wave, wave + 8 (input block t >> 2, output block t & 3); db2
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int t = wave + 8 * q;
+            lds_tile_mma<false, false, BM>(g2[q], sH1, LH, (t >> 2) * 32, sH2, LH, (t & 3) * 32, lane);
+        }
+        if (tid < H) {
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll 8
+            for (int r = 0; r < BM; r += 2) {
+                s0 += sH2[r * LH + tid];
+                s1 += sH2[(r + 1) * LH + tid];
+            }
+            db2r += s0 + s1;
+        }
+        // ---- dz1 = (dz2 W2^T) * (h1 > 0) / keep1 -> HBM
+        {
+            f32x16 a1; lds_zero(a1);
+            lds_tile_mma<true, true, H>(a1, sH2, LH, tm * 32, sW2, LH, tn * 32, lane);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = tm * 32 + lds_tile_row(r, h);
+                if (row < rows) {
+                    const float y = sH1[row * LH + col];
+                    p.dZ1[(long long)(row0 + row) * H + col] = (y > 0.f) ? a1[r] * p.scale1 : 0.f;
+                }
+            }
+        }
+        __syncthreads();     // the next slab overwrites h1 / h2
+    }
+
+    // ---- this workgroup's partial gradients
+    {
+        const int lane = tid0 & 63, wave = tid0 >> 6, li = lane & 31, h = lane >> 5;
+        float* base = p.slabs + (long long)blockIdx.x * p.slab_stride;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int t = wave + 8 * q;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                base[((t >> 2) * 32 + lds_tile_row(r, h)) * H + (t & 3) * 32 + li] = g2[q][r];
+        }
+        if (tid0 < H) base[H * H + tid0] = db2r;
+        if (wave < 4 && li < C) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) base[H * H + H + (wave * 32 + lds_tile_row(r, h)) * C + li] = g3[r];
+        }
+        if (tid0 < C) base[H * H + H + H * C + tid0] = db3r;
+        if (p.stats) {
+            const float l = dtf_wave_sum(loss), a = dtf_wave_sum(correct), n = dtf_wave_sum(count);
+            if (wave == 0 && lane == 0) {          // rows live on threads 0..63 = wave 0 only
+                atomicAdd(p.stats + 0, l);
+                atomicAdd(p.stats + 1, a);
+                atomicAdd(p.stats + 2, n);
+            }
+        }
+    }
+}
+
+// out[i] = sum over the workgroups' slabs, scattered to the four gradient tensors.  A 1024-thread block covers 64
+// float4 columns with 16 slab-groups (one wave each); the 16 partial sums meet in LDS.
+__global__ __launch_bounds__(1024) void tail_reduce_kernel(const float* __restrict__ slabs, long long slab_stride, int nslabs,
+                                                           float* __restrict__ dW2, float* __restrict__ db2,
+                                                           float* __restrict__ dW3, float* __restrict__ db3, int C) {
+    __shared__ f32x4 part[16][64];
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int n_total = H * H + H + H * C + C;
+    const int i = (blockIdx.x * 64 + c) * 4;
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+    if (i < n_total) {                        // slab_stride is a multiple of 4 and >= n_total rounded up: in bounds
+        int s = g;
+        for (; s + 16 < nslabs; s += 32) {
+            a0 += *reinterpret_cast<const f32x4*>(slabs + (long long)s * slab_stride + i);
+            a1 += *reinterpret_cast<const f32x4*>(slabs + (long long)(s + 16) * slab_stride + i);
+        }
+        for (; s < nslabs; s += 16) a0 += *reinterpret_cast<const f32x4*>(slabs + (long long)s * slab_stride + i);
+    }
+    part[g][c] = a0 + a1;
+    __syncthreads();
+    if (g == 0 && i < n_total) {
+        f32x4 t = part[0][c];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) t += part[k][c];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int e = i + j;
+            if (e >= n_total) break;
+            if (e < H * H) { dW2[e] = t[j]; continue; }
+            e -= H * H;
+            if (e < H) { db2[e] = t[j]; continue; }
+            e -= H;
+            if (e < H * C) { dW3[e] = t[j]; continue; }
+            db3[e - H * C] = t[j];
+        }
+    }
+}
+
+inline long long slab_stride_for(int C) {
+    const long long n = (long long)H * H + H + (long long)H * C + C;
+    return (n + 3) / 4 * 4;
+}
+inline int grid_for(int M) {
+    const int nslabs = (M + BM - 1) / BM;
+    return nslabs < 256 ? nslabs : 256;     // one persistent workgroup per CU
+}
+
+}  // namespace
+
+DTF_API int dtf_mlp_tail_supported(int H1, int H2, int C) { return (H1 == H && H2 == H && C >= 1 && C <= CP) ? 1 : 0; }
+
+DTF_API long long dtf_mlp_tail_workspace_floats(int M, int C) { return (long long)grid_for(M) * slab_stride_for(C); }
+
+// Forward from h1 through the loss and backward to dz1 / dW2 / db2 / dW3 / db3 (see the file header).
+DTF_API int dtf_mlp_tail(const float* H1, const float* W2, const float* b2, const float* W3, const float* b3,
+                         const long long* labels, float* dZ1, float* dW2, float* db2, float* dW3, float* db3,
+                         float* workspace, long long workspace_floats, int M, int H1dim, int H2dim, int C, float keep2,
+                         uint32_t seed2, const long long* step_ptr, float scale1, float grad_scale, float* stats,
+                         hipStream_t stream) {
+    if (!dtf_mlp_tail_supported(H1dim, H2dim, C)) return -4;
+    if (M <= 0) return 0;
+    const int grid = grid_for(M);
+    const long long stride = slab_stride_for(C);
+    if (workspace_floats < (long long)grid * stride) return -7;
+    TailArgs a = {};
+    a.H1 = H1; a.W2 = W2; a.b2 = b2; a.W3 = W3; a.b3 = b3; a.labels = labels; a.dZ1 = dZ1;
+    a.slabs = workspace; a.slab_stride = stride; a.M = M; a.C = C; a.keep2 = keep2; a.seed2 = seed2;
+    a.step_ptr = step_ptr; a.scale1 = scale1; a.grad_scale = grad_scale; a.stats = stats;
+    constexpr size_t lds = sizeof(float) * LDS_FLOATS;
+    static bool once = false;
+    if (!once) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_tail_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        once = true;
+    }
+    hipLaunchKernelGGL(mlp_tail_kernel, dim3(grid), dim3(NT), lds, stream, a);
+    DTF_CHECK_LAUNCH();
+    const int n_total = H * H + H + H * C + C;
+    hipLaunchKernelGGL(tail_reduce_kernel, dim3((n_total + 255) / 256), dim3(1024), 0, stream, workspace, stride, grid, dW2,
+                       db2, dW3, db3, C);
+    DTF_CHECK_LAUNCH();
+    return 0;
+}

@@ -15,10 +15,37 @@
 
 namespace {
 
+// Optional tail of an apply kernel: the LAST workgroup to finish advances global_step (and TF's beta-power
+// variables), which saves a separate one-thread launch per training step.  Every workgroup has read *step_ptr
+// before it takes its ticket, so the increment cannot be seen by a workgroup of the same launch.
+struct Advance {
+    long long* step;        // null: do not advance
+    float* beta_powers;     // [2] or null
+    unsigned int* ticket;   // device counter, zero between launches
+    float b1, b2;
+};
+
+__device__ __forceinline__ void advance_if_last(const Advance& a) {
+    if (!a.step) return;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const unsigned int t = atomicAdd(a.ticket, 1u);
+        if (t == gridDim.x - 1) {
+            *a.ticket = 0u;
+            *a.step += 1;
+            if (a.beta_powers) {
+                a.beta_powers[0] *= a.b1;
+                a.beta_powers[1] *= a.b2;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ var, float* __restrict__ m,
                                                    float* __restrict__ v, const float* __restrict__ g,
                                                    long long n, float lr, float b1, float b2, float eps,
-                                                   float grad_scale, const long long* __restrict__ step_ptr) {
+                                                   float grad_scale, const long long* step_ptr, const Advance adv) {
     const float t = (float)(*step_ptr + 1);
     const float b1t = powf(b1, t), b2t = powf(b2, t);
     const float lr_t = lr * sqrtf(1.0f - b2t) / (1.0f - b1t);
@@ -51,12 +78,13 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ var, floa
         v[i] = vj;
         var[i] -= lr_t * mj / (sqrtf(vj) + eps);
     }
+    advance_if_last(adv);
 }
 
 // var <- var - lr * (momentum-filtered) g.  mom == nullptr: plain SGD (tf.train.GradientDescentOptimizer).
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ var, float* __restrict__ mom,
                                                   const float* __restrict__ g, long long n, float lr,
-                                                  float momentum, float grad_scale) {
+                                                  float momentum, float grad_scale, const Advance adv) {
     const long long n4 = n >> 2;
     const long long stride = (long long)gridDim.x * blockDim.x;
     const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -87,6 +115,7 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ var, float
         }
         var[i] -= lr * gj;
     }
+    advance_if_last(adv);
 }
 
 // global_step += 1 and the TF non-slot variables beta1_power / beta2_power *= beta.
@@ -108,26 +137,32 @@ inline int flat_grid(long long n) {
 
 }  // namespace
 
+// advance_step (nullable) is incremented once by the launch's last workgroup; it needs `ticket`, a zeroed device
+// counter that only these kernels touch.
 DTF_API int dtf_adam_apply(float* var, float* m, float* v, const float* g, long long n, float lr, float b1,
-                           float b2, float eps, float grad_scale, const long long* step_ptr,
-                           hipStream_t stream) {
+                           float b2, float eps, float grad_scale, const long long* step_ptr, long long* advance_step,
+                           float* beta_powers, unsigned int* ticket, hipStream_t stream) {
     if (n <= 0) return 0;
+    if (advance_step && !ticket) return -3;
+    const Advance adv = {advance_step, beta_powers, ticket, b1, b2};
     if ((reinterpret_cast<uintptr_t>(var) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v) |
          reinterpret_cast<uintptr_t>(g)) & 15)
         return -2;  // flat buffers and shard boundaries are 16-byte aligned by construction
     hipLaunchKernelGGL(adam_kernel, dim3(flat_grid(n)), dim3(256), 0, stream, var, m, v, g, n, lr, b1, b2, eps,
-                       grad_scale, step_ptr);
+                       grad_scale, step_ptr, adv);
     DTF_CHECK_LAUNCH();
     return 0;
 }
 
 DTF_API int dtf_sgd_apply(float* var, float* mom, const float* g, long long n, float lr, float momentum,
-                          float grad_scale, hipStream_t stream) {
+                          float grad_scale, long long* advance_step, unsigned int* ticket, hipStream_t stream) {
     if (n <= 0) return 0;
+    if (advance_step && !ticket) return -3;
+    const Advance adv = {advance_step, nullptr, ticket, 0.f, 0.f};
     if ((reinterpret_cast<uintptr_t>(var) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(mom)) & 15)
         return -2;
     hipLaunchKernelGGL(sgd_kernel, dim3(flat_grid(n)), dim3(256), 0, stream, var, mom, g, n, lr, momentum,
-                       grad_scale);
+                       grad_scale, adv);
     DTF_CHECK_LAUNCH();
     return 0;
 }

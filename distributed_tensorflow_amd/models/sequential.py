@@ -52,8 +52,7 @@ class LocalStrategy:
         pass
 
     def apply_gradients(self, model):
-        model.optimizer.apply(model.store)
-        model.optimizer.finish_step(model.store)
+        model.optimizer.apply_and_finish(model.store)
 
     def reduce_stats(self, stats: torch.Tensor) -> torch.Tensor:
         return stats
@@ -77,6 +76,8 @@ class Sequential:
         self._host_step = 0           # host mirror of global_step (no device sync needed)
         self._graphs: Dict = {}
         self._fused_plans: Dict = {}
+        self._tail_plan = False       # False = not looked at yet
+        self.use_tail_kernel = True   # set False to force the layer-by-layer kernels through the network's tail
         self._after_layer_backward = None   # strategy hook: called as each layer's gradients become final
         for layer in layers or []:
             self.add(layer)
@@ -201,8 +202,68 @@ class Sequential:
                                        stats[3:4])
         return g
 
+    # ------------------------------------------------------------------ fused network tail
+    def tail_plan(self):
+        """(index of the first tail layer, Dense b, Dense c) when the model ends in
+        ``Dense(128, relu)[+Dropout] -> Dense(128, relu)[+Dropout] -> Dense(C <= 16, softmax)`` trained with sparse
+        softmax cross-entropy on the GPU: everything after the first of those three layers (forward, loss, backward
+        down to that layer's dL/dz) then runs in one kernel, ``csrc/kernels/mlp_tail.hip``.  ``None`` otherwise."""
+        if self._tail_plan is not False:
+            return self._tail_plan
+        self._tail_plan = None
+        eff = self._effective
+        if not self.use_tail_kernel or self.device is None or self.device.type != "cuda" or len(eff) < 3:
+            return None
+        a, b, c = eff[-3], eff[-2], eff[-1]
+        if not (isinstance(a, Dense) and isinstance(b, Dense) and isinstance(c, Dense)):
+            return None
+        if not isinstance(self.loss, losses_mod.SparseCategoricalCrossentropy) or not c.emit_logits or c.act != ACT_NONE:
+            return None
+        if a.act != ACT_RELU or a.softmax or b.act != ACT_RELU or b.softmax or not b.fuse_prev_grad or not a.grad_is_dz:
+            return None
+        if b.bias is None or c.bias is None or c.fused_keep < 1.0 or not c.fuse_prev_grad:
+            return None
+        ia = self.layers.index(a)
+        rest = self.layers[ia + 1:]
+        if any(not (l is b or l is c or (isinstance(l, Dropout) and l.fused_into_previous)) for l in rest):
+            return None
+        if not F.mlp_tail_supported(a.units, b.units, c.units):
+            return None
+        self._tail_plan = (ia + 1, b, c)
+        return self._tail_plan
+
+    def _compute_gradients_tail(self, x, y, stats, plan):
+        first, b, c = plan
+        h = x
+        for layer in self.layers[:first]:
+            h = layer.forward(h, True)
+        M = h.shape[0]
+        key = ("tail", M, str(h.device))
+        bufs = self._grad_buf.get(key)
+        if bufs is None:
+            bufs = (torch.empty((M, b.kernel.shape[0]), dtype=torch.float32, device=h.device),
+                    torch.empty(F.mlp_tail_workspace_floats(M, c.units), dtype=torch.float32, device=h.device))
+            self._grad_buf[key] = bufs
+        dz1, ws = bufs
+        F.mlp_tail(h, b.kernel.tensor, b.bias.tensor, c.kernel.tensor, c.bias.tensor, y, dz1, b.kernel.grad, b.bias.grad,
+                   c.kernel.grad, c.bias.grad, ws, b.fused_keep, b.seed, self.store.global_step, b.prev_scale, 1.0 / M, stats)
+        hook = self._after_layer_backward
+        if hook is not None:
+            hook(c, self)
+            hook(b, self)
+        g = dz1
+        for layer in reversed(self.layers[:first]):
+            g = layer.backward(g)
+            if hook is not None:
+                hook(layer, self)
+            if g is None:
+                break
+
     def compute_gradients(self, x, y, stats: Optional[torch.Tensor] = None):
         """Forward + loss + backward: leaves dL/dvar in ``store.flat_grad`` (no variable update)."""
+        plan = self.tail_plan() if (x.is_cuda and y.dtype == torch.int64 and y.dim() == 1) else None
+        if plan is not None:
+            return self._compute_gradients_tail(x, y.contiguous(), self.stats if stats is None else stats, plan)
         out = self.forward(x, training=True)
         g = self._loss_and_metrics(out, y, True, self.stats if stats is None else stats)
         self.backward(g)
@@ -297,7 +358,7 @@ class Sequential:
         torch.cuda.synchronize()
         self._restore(saved)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):   # other threads (RCCL watchdog) keep working
             for k in range(nsteps):
                 self.train_step(x_buf[k * batch_size:(k + 1) * batch_size],
                                 y_buf[k * batch_size:(k + 1) * batch_size])
@@ -325,7 +386,7 @@ class Sequential:
         torch.cuda.synchronize()
         self.stats.copy_(saved_stats)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):   # other threads (RCCL watchdog) keep working
             self.compute_gradients(x_buf, y_buf)
         self._graphs[key] = g
         return g

@@ -58,8 +58,8 @@ def kernels():
         "dtf_mse_loss": [c_p, c_p, c_p, c_i, c_i, c_f, c_i, c_p, c_p],
         "dtf_softmax_xent": [c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_p, c_p],
         "dtf_categorical_accuracy": [c_p, c_p, c_i, c_i, c_p, c_p],
-        "dtf_adam_apply": [c_p, c_p, c_p, c_p, c_ll, c_f, c_f, c_f, c_f, c_f, c_p, c_p],
-        "dtf_sgd_apply": [c_p, c_p, c_p, c_ll, c_f, c_f, c_f, c_p],
+        "dtf_adam_apply": [c_p, c_p, c_p, c_p, c_ll, c_f, c_f, c_f, c_f, c_f, c_p, c_p, c_p, c_p, c_p],
+        "dtf_sgd_apply": [c_p, c_p, c_p, c_ll, c_f, c_f, c_f, c_p, c_p, c_p],
         "dtf_step_advance": [c_p, c_p, c_f, c_f, c_p],
         "dtf_act_grad": [c_p, c_p, c_p, c_ll, c_i, c_f, c_p],
         "dtf_dropout": [c_p, c_p, c_ll, c_f, c_u32, c_p, c_p],
@@ -71,6 +71,8 @@ def kernels():
         "dtf_col2im": [c_p, c_p, c_p] + [c_i] * 12 + [c_p],
         "dtf_maxpool_fwd": [c_p, c_p, c_p] + [c_i] * 6 + [c_p],
         "dtf_maxpool_bwd": [c_p, c_p, c_p, c_p] + [c_i] * 6 + [c_p],
+        "dtf_mlp_tail_supported": [c_i, c_i, c_i],
+        "dtf_mlp_tail": [c_p] * 12 + [c_ll, c_i, c_i, c_i, c_i, c_f, c_u32, c_p, c_f, c_f, c_p, c_p],
         "dtf_mlp3_fused_supported": [c_i, c_i, c_i, c_i, c_i],
         "dtf_mlp3_fused_train": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
                                  c_f, c_f, c_u32, c_u32, c_f, c_f, c_f, c_f, c_p, c_p, c_p, c_p],

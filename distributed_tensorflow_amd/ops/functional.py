@@ -304,15 +304,31 @@ def categorical_accuracy_sum(p, y, acc_sum):
 
 
 # --------------------------------------------------------------------------- optimizers
-def adam_apply(var, m, v, grad, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
-    """TensorFlow-formula Adam on flat fp32 ranges; ``step`` is the int64 global_step BEFORE this update."""
+_tickets = {}
+
+
+def _ticket(device) -> torch.Tensor:
+    """Zeroed device counter the apply kernels use to elect their last workgroup (one per device)."""
+    key = str(device)
+    t = _tickets.get(key)
+    if t is None:
+        t = torch.zeros(1, dtype=torch.int32, device=device)
+        _tickets[key] = t
+    return t
+
+
+def adam_apply(var, m, v, grad, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, advance=None,
+               beta_powers=None):
+    """TensorFlow-formula Adam on flat fp32 ranges; ``step`` is the int64 global_step BEFORE this update.
+    ``advance`` (the global_step tensor, or None): also do ``step_advance`` at the end of the same launch."""
     n = var.numel()
     assert m.numel() == n and v.numel() == n and grad.numel() == n
     if var.is_cuda:
         nv.require_f32_contig(var, m, v, grad)
         rc = nv.kernels().dtf_adam_apply(nv.ptr(var), nv.ptr(m), nv.ptr(v), nv.ptr(grad), n, float(lr),
                                          float(beta1), float(beta2), float(eps), float(grad_scale),
-                                         nv.ptr(step), nv.stream_ptr())
+                                         nv.ptr(step), nv.ptr(advance), nv.ptr(beta_powers if advance is not None else None),
+                                         nv.ptr(_ticket(var.device)) if advance is not None else 0, nv.stream_ptr())
         nv.check(rc, "dtf_adam_apply")
         return var
     t = float(_step_value(step) + 1)
@@ -323,16 +339,20 @@ def adam_apply(var, m, v, grad, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8,
     m.mul_(beta1).add_(g, alpha=1.0 - beta1)
     v.mul_(beta2).addcmul_(g, g, value=1.0 - beta2)
     var.sub_(lr_t * m / (v.sqrt() + eps))
+    if advance is not None:
+        step_advance(advance, beta_powers, beta1, beta2)
     return var
 
 
-def sgd_apply(var, grad, lr, momentum_buf=None, momentum=0.0, grad_scale=1.0):
-    """``var -= lr * g`` (optionally with a classical momentum accumulator) on flat fp32 ranges."""
+def sgd_apply(var, grad, lr, momentum_buf=None, momentum=0.0, grad_scale=1.0, advance=None):
+    """``var -= lr * g`` (optionally with a classical momentum accumulator) on flat fp32 ranges.
+    ``advance`` (the global_step tensor, or None): also increment it at the end of the same launch."""
     n = var.numel()
     if var.is_cuda:
         nv.require_f32_contig(var, grad, momentum_buf)
         rc = nv.kernels().dtf_sgd_apply(nv.ptr(var), nv.ptr(momentum_buf), nv.ptr(grad), n, float(lr),
-                                        float(momentum), float(grad_scale), nv.stream_ptr())
+                                        float(momentum), float(grad_scale), nv.ptr(advance),
+                                        nv.ptr(_ticket(var.device)) if advance is not None else 0, nv.stream_ptr())
         nv.check(rc, "dtf_sgd_apply")
         return var
     g = grad * grad_scale
@@ -340,6 +360,8 @@ def sgd_apply(var, grad, lr, momentum_buf=None, momentum=0.0, grad_scale=1.0):
         momentum_buf.mul_(momentum).add_(g)
         g = momentum_buf
     var.sub_(lr * g)
+    if advance is not None:
+        step_advance(advance)
     return var
 
 
@@ -511,3 +533,40 @@ def maxpool_backward(dy, arg, x_shape, pool=(2, 2), x_relu=None, out=None):
     if x_relu is not None:
         out.mul_((x_relu > 0).to(out.dtype))
     return out
+
+
+# ----------------------------------------------------------------------------- fused network tail
+def mlp_tail_supported(h1: int, h2: int, classes: int) -> bool:
+    """True when csrc/kernels/mlp_tail.hip covers Dense(h1->h2, relu[, dropout]) -> Dense(h2->classes) -> sparse
+    softmax cross-entropy."""
+    if not nv.kernels_available():
+        return False
+    lib = nv.kernels()
+    return hasattr(lib, "dtf_mlp_tail_supported") and bool(lib.dtf_mlp_tail_supported(int(h1), int(h2), int(classes)))
+
+
+def mlp_tail_workspace_floats(M: int, classes: int) -> int:
+    import ctypes as C
+    fn = nv.declare(nv.kernels(), "dtf_mlp_tail_workspace_floats", [C.c_int, C.c_int], C.c_longlong)
+    return int(fn(int(M), int(classes)))
+
+
+def mlp_tail(h1, w2, b2, w3, b3, labels, dz1, dw2, db2, dw3, db3, workspace, keep2, seed2, step, scale1, grad_scale,
+             stats):
+    """Forward from ``h1`` through the softmax cross-entropy and backward to ``dz1`` / ``dw2`` / ``db2`` / ``dw3`` /
+    ``db3`` in one fused kernel (plus two slab reductions); GPU only."""
+    M, H1 = h1.shape
+    H2, C = w3.shape
+    nv.require_f32_contig(h1, w2, b2, w3, b3, dz1, dw2, db2, dw3, db3, workspace)
+    if not h1.is_cuda:
+        raise ValueError("the fused tail kernel runs on the GPU only")
+    if labels.dtype != torch.int64 or labels.shape != (M,) or not labels.is_contiguous():
+        raise ValueError("fused tail: labels must be a contiguous int64 vector of length %d" % M)
+    if tuple(w2.shape) != (H1, H2) or tuple(dz1.shape) != (M, H1) or tuple(dw2.shape) != (H1, H2) or \
+            tuple(dw3.shape) != (H2, C) or b2.numel() != H2 or b3.numel() != C or db2.numel() != H2 or db3.numel() != C:
+        raise ValueError("fused tail: inconsistent operand shapes")
+    rc = nv.kernels().dtf_mlp_tail(
+        nv.ptr(h1), nv.ptr(w2), nv.ptr(b2), nv.ptr(w3), nv.ptr(b3), nv.ptr(labels), nv.ptr(dz1), nv.ptr(dw2), nv.ptr(db2),
+        nv.ptr(dw3), nv.ptr(db3), nv.ptr(workspace), int(workspace.numel()), int(M), int(H1), int(H2), int(C),
+        float(keep2), int(seed2) & _M32, nv.ptr(step), float(scale1), float(grad_scale), nv.ptr(stats), nv.stream_ptr())
+    nv.check(rc, "dtf_mlp_tail")

@@ -31,6 +31,11 @@ class Optimizer:
     def create_slots(self, store: VariableStore):
         pass
 
+    def apply_and_finish(self, store: VariableStore, grad_scale: float = 1.0):
+        """Whole-buffer update plus the ``global_step`` increment (one launch where the optimizer can fuse them)."""
+        self.apply(store, grad_scale=grad_scale)
+        self.finish_step(store)
+
 
 class Adam(Optimizer):
     slot_checkpoint_names = {"m": "Adam", "v": "Adam_1"}
@@ -58,6 +63,10 @@ class Adam(Optimizer):
     def finish_step(self, store):
         F.step_advance(store.global_step, store.beta_powers, self.beta1, self.beta2)
 
+    def apply_and_finish(self, store, grad_scale=1.0):
+        F.adam_apply(store.flat, store.slot("m"), store.slot("v"), store.flat_grad, store.global_step, self.lr, self.beta1,
+                     self.beta2, self.epsilon, grad_scale, advance=store.global_step, beta_powers=store.beta_powers)
+
 
 class SGD(Optimizer):
     slot_checkpoint_names = {"momentum": "Momentum"}
@@ -76,6 +85,10 @@ class SGD(Optimizer):
         g = store.flat_grad if grad is None else grad
         mom = store.slot("momentum")[begin:end] if self.momentum > 0.0 else None
         F.sgd_apply(store.flat[begin:end], g[begin:end], self.lr, mom, self.momentum, grad_scale)
+
+    def apply_and_finish(self, store, grad_scale=1.0):
+        mom = store.slot("momentum") if self.momentum > 0.0 else None
+        F.sgd_apply(store.flat, store.flat_grad, self.lr, mom, self.momentum, grad_scale, advance=store.global_step)
 
 
 # TF 1.x class names (tf.train.*)

@@ -161,8 +161,7 @@ class SyncReplicasStrategy:
                 work = c.all_reduce_sum(store.flat_grad, async_op=(c.backend == "nccl"))
             if work is not None and hasattr(work, "wait"):
                 work.wait()            # stream-level wait under RCCL: the host does not block
-        model.optimizer.apply(store, grad_scale=scale)
-        model.optimizer.finish_step(store)
+        model.optimizer.apply_and_finish(store, grad_scale=scale)
 
     def apply_gradients(self, model):
         store = model.store
