@@ -115,7 +115,17 @@ bool wait_until(State& st, std::unique_lock<std::mutex>& lk, int64_t timeout_ms,
         st.cv.wait(lk, [&] { return st.stopping || pred(); });
         return pred();
     }
-    return st.cv.wait_for(lk, std::chrono::milliseconds(timeout_ms), [&] { return st.stopping || pred(); }) && pred();
+    // Deadline on the steady clock, sleeping in slices of pthread_cond_timedwait (system clock): a wall-clock jump
+    // distorts at most one slice, and ThreadSanitizer sees the mutex hand-off (GCC 11's runtime does not intercept
+    // the steady-clock wait that wait_for would use and then reports false races).
+    const auto deadline = Clock::now() + std::chrono::milliseconds(timeout_ms);
+    while (!(st.stopping || pred())) {
+        const auto left = deadline - Clock::now();
+        if (left <= Clock::duration::zero()) break;
+        const auto slice = std::min<Clock::duration>(left, std::chrono::milliseconds(200));
+        st.cv.wait_until(lk, std::chrono::system_clock::now() + std::chrono::duration_cast<std::chrono::microseconds>(slice));
+    }
+    return pred();
 }
 
 struct Server {
@@ -278,9 +288,10 @@ struct Server {
         socklen_t sl = sizeof(addr);
         getsockname(listen_fd, reinterpret_cast<sockaddr*>(&addr), &sl);
         port = ntohs(addr.sin_port);
-        accept_thread = std::thread([this] {
+        const int lfd = listen_fd;       // the accept thread works on its own copy; stop() owns the member
+        accept_thread = std::thread([this, lfd] {
             for (;;) {
-                int fd = ::accept(listen_fd, nullptr, nullptr);
+                int fd = ::accept(lfd, nullptr, nullptr);
                 if (fd < 0) {
                     if (errno == EINTR) continue;
                     break;
@@ -299,12 +310,12 @@ struct Server {
             st.stopping = true;
             st.cv.notify_all();
         }
+        if (listen_fd >= 0) ::shutdown(listen_fd, SHUT_RDWR);      // wakes accept(); the descriptor stays valid until
+        if (accept_thread.joinable()) accept_thread.join();        // the accept thread is gone
         if (listen_fd >= 0) {
-            ::shutdown(listen_fd, SHUT_RDWR);
             ::close(listen_fd);
             listen_fd = -1;
         }
-        if (accept_thread.joinable()) accept_thread.join();
         std::vector<std::thread> threads;
         {
             std::lock_guard<std::mutex> g(conn_mu);

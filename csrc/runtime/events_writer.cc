@@ -107,7 +107,9 @@ struct EventsWriter {
         auto last_flush = std::chrono::steady_clock::now();
         std::unique_lock<std::mutex> lk(mu);
         for (;;) {
-            cv.wait_for(lk, std::chrono::milliseconds(200), [&] { return closing || flush_requested || !queue.empty(); });
+            // system-clock wait (pthread_cond_timedwait): a 200 ms slice, and visible to ThreadSanitizer
+            cv.wait_until(lk, std::chrono::system_clock::now() + std::chrono::milliseconds(200),
+                          [&] { return closing || flush_requested || !queue.empty(); });
             std::deque<std::string> batch;
             batch.swap(queue);
             const bool do_flush = flush_requested || closing ||

@@ -109,6 +109,28 @@ def build_runtime(verbose: bool = True) -> Path:
     return out
 
 
+def build_runtime_stress(sanitizer: str = "thread", verbose: bool = True) -> Path:
+    """Host-only stress executable of the C++ runtime (control plane + event writer) instrumented with a sanitizer
+    (``thread`` or ``address``); returns its path.  Sanitizers apply to host code only - GPU code is not involved."""
+    if sanitizer not in ("thread", "address", "undefined"):
+        raise ValueError("sanitizer must be thread, address or undefined")
+    out_dir = ROOT / "build" / "bin"
+    out_dir.mkdir(parents=True, exist_ok=True)
+    out = out_dir / ("stress_runtime_%s" % sanitizer)
+    sources = [CSRC / "runtime" / "tests" / "stress_runtime.cc", CSRC / "runtime" / "control_plane.cc",
+               CSRC / "runtime" / "events_writer.cc", CSRC / "runtime" / "crc32c.cc"]
+    stamp = out_dir / (out.name + ".stamp")
+    want = _digest(sources + sorted((CSRC / "runtime").glob("*.h")))
+    if out.exists() and stamp.exists() and stamp.read_text() == want:
+        return out
+    if verbose:
+        print("[build] %s -fsanitize=%s stress_runtime" % (Path(CXX).name, sanitizer), flush=True)
+    _run([CXX, "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=" + sanitizer, "-fno-omit-frame-pointer",
+          "-I", str(CSRC / "runtime"), *map(str, sources), "-o", str(out)])
+    stamp.write_text(want)
+    return out
+
+
 def build_all(verbose: bool = True):
     return build_kernels(verbose), build_runtime(verbose)
 
