@@ -20,8 +20,9 @@ NAMES = ["batch->LDS", "L1 fwd", "L2 chunk0 (+commit)", "L2 chunk1 + epilogue", 
 def main():
     dev = torch.device("cuda", 0)
     B, steps = int(os.environ.get("B", "50")), 200
-    m = xor_mlp()
-    m.compile(loss="mean_squared_error", optimizer="adam", metrics=["binary_rounded_accuracy"], device=dev, seed=0)
+    m = xor_mlp(dropout=float(os.environ.get("DROPOUT", "0.3")))
+    m.compile(loss="mean_squared_error", optimizer=os.environ.get("OPT", "adam"), metrics=["binary_rounded_accuracy"],
+              device=dev, seed=0)
     x, y = get_data(B * steps, val_set_size=0, seed=1, device=dev)[:2]
     prof = torch.zeros(16, dtype=torch.int64, device=dev)
     lib = _native.kernels()
@@ -36,6 +37,7 @@ def main():
     lib.dtf_mlp3_fused_set_profile_buffer(None)
     t = prof.tolist()
     total = t[12] - t[0]
+    print("dropout=%s opt=%s" % (os.environ.get("DROPOUT", "0.3"), os.environ.get("OPT", "adam")))
     print("B=%d  %.2f us/step wall (%d steps/launch); last step = %d shader-clock ticks" % (B, 1e6 * dt / steps, steps, total))
     for i, name in enumerate(NAMES):
         d = t[i + 1] - t[i]

@@ -119,6 +119,8 @@ class Sequential:
                 L[i - 1].fused_keep = 1.0 - layer.rate
                 L[i - 1].seed = layer.seed
                 layer.fused_into_previous = True
+            elif isinstance(layer, Dropout) and layer.rate == 0.0:
+                layer.fused_into_previous = True      # a no-op: leave it out of the effective chain
         # chain of "effective" layers (skipping folded dropouts)
         eff = [l for l in L if not (isinstance(l, Dropout) and l.fused_into_previous)]
         for a, b in zip(eff[:-1], eff[1:]):
