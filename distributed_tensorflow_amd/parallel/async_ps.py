@@ -90,12 +90,30 @@ def _unpack(buf: torch.Tensor, flat: torch.Tensor, ranges):
 
 # --------------------------------------------------------------------------- data-plane helper
 class _P2P:
-    """send/recv between global ranks with the loop-back (same process) case short-circuited."""
+    """send/recv between global ranks with the loop-back (same process) case short-circuited.
+
+    RCCL matches the sends and receives of a pair of ranks purely by issue order (message tags are ignored), and a
+    process here has two threads talking to the same peers - the worker thread (gradients out, parameters in) and,
+    when owners are colocated, the owner thread (gradients in, parameters out).  Each direction therefore gets its
+    own communicator: on ``push`` only worker threads send and only owner threads receive, on ``pull`` the reverse,
+    so every (source, destination) pair of a communicator carries one strictly ordered stream.
+    """
 
     def __init__(self, rank: int):
         self.rank = rank
         self.mail: Dict[Tuple[int, int], List[torch.Tensor]] = {}
         self.cv = threading.Condition()
+        self.push_group = None      # worker -> owner (gradients, initial values)
+        self.pull_group = None      # owner -> worker (parameters)
+
+    def make_direction_groups(self):
+        """Collective over the whole process group: every member calls this once, right after joining."""
+        if self.push_group is None and dist.is_initialized() and dist.get_world_size() > 1:
+            self.push_group = dist.new_group()
+            self.pull_group = dist.new_group()
+
+    def _group(self, tag: int):
+        return self.pull_group if tag == _TAG_PULL else self.push_group
 
     def send(self, t: torch.Tensor, dst: int, tag: int):
         if dst == self.rank:
@@ -104,7 +122,7 @@ class _P2P:
                 self.cv.notify_all()
             return
         with _NCCL_LOCK:
-            w = dist.isend(t, dst=dst, tag=tag)
+            w = dist.isend(t, dst=dst, tag=tag, group=self._group(tag))
         w.wait()
 
     def recv(self, t: torch.Tensor, src: int, tag: int):
@@ -115,7 +133,7 @@ class _P2P:
                 t.copy_(self.mail[(tag, 0)].pop(0))
             return
         with _NCCL_LOCK:
-            w = dist.irecv(t, src=src, tag=tag)
+            w = dist.irecv(t, src=src, tag=tag, group=self._group(tag))
         w.wait()
 
 
@@ -127,23 +145,25 @@ class _P2P:
         On NCCL the operations are issued as one group (they progress concurrently on the stream).
         """
         local_recvs = []
-        ops = []
+        send_ops, recv_ops = [], []
         for t, dst, tag in sends:
             if dst == self.rank:
                 with self.cv:
                     self.mail.setdefault((tag, 0), []).append(t.clone())
                     self.cv.notify_all()
             else:
-                ops.append(dist.P2POp(dist.isend, t, dst, tag=tag))
+                send_ops.append(dist.P2POp(dist.isend, t, dst, group=self._group(tag), tag=tag))
         for t, src, tag in recvs:
             if src == self.rank:
                 local_recvs.append((t, tag))
             else:
-                ops.append(dist.P2POp(dist.irecv, t, src, tag=tag))
+                recv_ops.append(dist.P2POp(dist.irecv, t, src, group=self._group(tag), tag=tag))
         works = []
-        if ops:
-            with _NCCL_LOCK:
-                works = dist.batch_isend_irecv(ops)
+        with _NCCL_LOCK:           # one batch per communicator (a batch may not mix groups)
+            if send_ops:
+                works += dist.batch_isend_irecv(send_ops)
+            if recv_ops:
+                works += dist.batch_isend_irecv(recv_ops)
         for t, tag in local_recvs:
             with self.cv:
                 while not self.mail.get((tag, 0)):
@@ -241,6 +261,7 @@ class ParameterServerService:
         if self.p2p is None:
             self._join_data_plane()      # only clusters that use their ps tasks put them on the data plane
             self.p2p = _P2P(self.rank)
+            self.p2p.make_direction_groups()
         self._configure(layout)
         self.cp.add("ps/ready", 1)
         while True:
@@ -416,6 +437,7 @@ class AsyncPSStrategy:
             rank = self.worker_index if self.colocated else srv.rank
             init_process_group(backend, rank=rank, world_size=world, master_addr=host, master_port=port,
                                device=dev if backend == "nccl" else None)
+        self.p2p.make_direction_groups()
         if self._service_thread is not None:
             self._service_thread.start()
         # chief initialises the owners, everybody else waits (chief-initialises / others-wait)
