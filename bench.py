@@ -44,6 +44,9 @@ def parse_args():
     ap.add_argument("--bucket-mb", type=float, default=64.0)
     ap.add_argument("--width", type=int, default=16384, help="wide_mlp hidden width")
     ap.add_argument("--depth", type=int, default=5, help="wide_mlp hidden depth")
+    ap.add_argument("--mode", default="sync", choices=["sync", "async"],
+                    help="sync: synchronous replicas (headline); async: parameter-server mode, owners colocated with workers")
+    ap.add_argument("--max-staleness", type=int, default=4, help="async mode: bound on worker clock skew (-1 = unbounded)")
     ap.add_argument("--single-rank-collectives", type=int, default=0,
                     help="testing aid: run the multi-GPU code path (RCCL calls included) on a 1-rank process group")
     ap.add_argument("--eval", type=int, default=0, help="also train for this many extra steps and report test accuracy")
@@ -75,7 +78,19 @@ def main():
 
     strategy = None
     multi = world > 1 or bool(args.single_rank_collectives)
-    if multi:
+    if args.mode == "async":
+        # asynchronous parameter-server mode with colocated owners: every rank is a worker AND owns 1/N of the
+        # flat variable buffer in its HBM; packed push / pull per owner per step, bounded staleness
+        from distributed_tensorflow_amd.cluster import ClusterSpec, Server
+        from distributed_tensorflow_amd.parallel.async_ps import AsyncPSStrategy
+        base = int(os.environ.get("MASTER_PORT", "29500")) + 16
+        if world > 1:
+            init_process_group("nccl", device=dev)
+        hosts = ["127.0.0.1:%d" % (base + i) for i in range(world)]
+        server = Server(ClusterSpec({"worker": hosts}), "worker", rank, config={"device": str(dev)})
+        strategy = AsyncPSStrategy(server, max_staleness=args.max_staleness if args.max_staleness >= 0 else None)
+        multi = world > 1
+    elif multi:
         if world == 1:
             os.environ["DTF_FORCE_COLLECTIVES"] = "1"
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -116,7 +131,7 @@ def main():
     x_all, y_all = make(B * pool, 1000 + rank)
     batches = [(x_all[i * B:(i + 1) * B], y_all[i * B:(i + 1) * B]) for i in range(pool)]
 
-    use_graph = plan is None and ((args.graph == 1) or (args.graph == -1 and not multi))
+    use_graph = plan is None and args.mode == "sync" and ((args.graph == 1) or (args.graph == -1 and not multi))
     graphs = grad_graphs = None
     if use_graph and not multi:
         graphs = [model._graphed_steps(bx, by, B, 1) for bx, by in batches]
@@ -175,11 +190,16 @@ def main():
         xt, yt = make(8192, 99)
         test_acc = model.evaluate(xt, yt, batch_size=8192)[1]
 
+    if args.mode == "async":
+        strategy.worker_done()
+        strategy.cp0.barrier("bench_done", world, timeout_s=300)
+        if rank == 0:
+            strategy.shutdown_owners()
     global_batch = B * world
     value = global_batch * args.steps / elapsed
     if rank == 0:
         out = {
-            "metric": "examples/sec (whole node) sync-DP MNIST-shape model",
+            "metric": "examples/sec (whole node) %s MNIST-shape model" % ("sync-DP" if args.mode == "sync" else "async-PS"),
             "value": value,
             "unit": "examples/s",
             "n_gpus": world,
@@ -192,13 +212,14 @@ def main():
             "dtype": "fp32",
             "data": "synthetic (device-resident MNIST-shaped inputs, random-init weights)",
             "config": {"model": args.model, "global_batch": global_batch, "batch_per_gpu": B, "seq_len": None,
-                       "parallelism": "dp%d" % world, "params": model.store.num_params,
+                       "parallelism": ("dp%d" if args.mode == "sync" else "async-ps%d") % world, "params": model.store.num_params,
                        "optimizer": "adam", "hip_graph": bool(use_graph), "fused_step_kernel": plan is not None,
                        "train_loss": logs.get("loss"), "train_acc": logs.get("acc"), "test_acc": test_acc},
         }
         print(json.dumps(out), flush=True)
     if multi:
         dist.barrier(device_ids=[dev.index])
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
