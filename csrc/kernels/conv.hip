@@ -199,3 +199,78 @@ DTF_API int dtf_maxpool_bwd(const float* dy, const unsigned char* arg, const flo
     DTF_CHECK_LAUNCH();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Helpers of the implicit-GEMM convolution path (stride 1): the GEMM kernels gather patch rows straight from a
+// zero-padded copy of the image, so the only per-step extra traffic is that copy (1.3-1.7x the image) instead of
+// the KH*KW-times larger patch matrix.
+namespace {
+
+// dst[b][h + pt][w + pl][c] = src[b][h][w][c], zero elsewhere; one thread per 4 channels of a padded pixel
+__global__ __launch_bounds__(256) void pad_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int H,
+                                                       int W, int C, int pt, int pl, int Hp, int Wp, long long total) {
+    const int CV = C / 4;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int c = (int)(idx % CV) * 4;
+        const long long pix = idx / CV;
+        const int wp = (int)(pix % Wp);
+        const int hp = (int)((pix / Wp) % Hp);
+        const int b = (int)(pix / ((long long)Wp * Hp));
+        const int h = hp - pt, w = wp - pl;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (h >= 0 && h < H && w >= 0 && w < W) v = *reinterpret_cast<const f32x4*>(src + (((long long)b * H + h) * W + w) * C + c);
+        *reinterpret_cast<f32x4*>(dst + pix * C + c) = v;
+    }
+}
+
+// rowtab[(b*OH + oh)*OW + ow] = ((b*Hp + oh)*Wp + ow) * C : origin of the patch of output pixel (b, oh, ow)
+__global__ __launch_bounds__(256) void conv_rowtab_kernel(int* __restrict__ rowtab, int B, int OH, int OW, int Hp, int Wp,
+                                                          int C, long long total) {
+    for (long long m = (long long)blockIdx.x * 256 + threadIdx.x; m < total; m += (long long)gridDim.x * 256) {
+        const int ow = (int)(m % OW);
+        const int oh = (int)((m / OW) % OH);
+        const int b = (int)(m / ((long long)OW * OH));
+        rowtab[m] = (int)((((long long)b * Hp + oh) * Wp + ow) * C);
+    }
+}
+
+// wflip[((KH-1-kh)*KW + (KW-1-kw))*N + n][c] = w[kh][kw][c][n]
+__global__ __launch_bounds__(256) void conv_flip_kernel(const float* __restrict__ w, float* __restrict__ wflip, int KH, int KW,
+                                                        int C, int N, int total) {
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        const int n = idx % N;
+        const int c = (idx / N) % C;
+        const int kw = (idx / (N * C)) % KW;
+        const int kh = idx / (N * C * KW);
+        wflip[(((KH - 1 - kh) * KW + (KW - 1 - kw)) * N + n) * C + c] = w[idx];
+    }
+}
+
+}  // namespace
+
+DTF_API int dtf_conv_pad(const float* src, float* dst, int B, int H, int W, int C, int pt, int pl, int Hp, int Wp,
+                         hipStream_t stream) {
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 || pt < 0 || pl < 0 || Hp < H + pt || Wp < W + pl) return -3;
+    if ((long long)B * Hp * Wp * C >= (1ll << 31)) return -8;        // offsets are 32-bit element indices
+    const long long total = (long long)B * Hp * Wp * (C / 4);
+    hipLaunchKernelGGL(pad_nhwc_kernel, dim3(grid_for(total)), dim3(256), 0, stream, src, dst, B, H, W, C, pt, pl, Hp, Wp, total);
+    DTF_CHECK_LAUNCH();
+    return 0;
+}
+
+DTF_API int dtf_conv_rowtab(int* rowtab, int B, int OH, int OW, int Hp, int Wp, int C, hipStream_t stream) {
+    if (B <= 0 || OH <= 0 || OW <= 0 || Hp < OH || Wp < OW || C <= 0) return -3;
+    if ((long long)B * Hp * Wp * C >= (1ll << 31)) return -8;
+    const long long total = (long long)B * OH * OW;
+    hipLaunchKernelGGL(conv_rowtab_kernel, dim3(grid_for(total)), dim3(256), 0, stream, rowtab, B, OH, OW, Hp, Wp, C, total);
+    DTF_CHECK_LAUNCH();
+    return 0;
+}
+
+DTF_API int dtf_conv_flip_weights(const float* w, float* wflip, int KH, int KW, int C, int N, hipStream_t stream) {
+    if (KH <= 0 || KW <= 0 || C <= 0 || N <= 0) return -3;
+    const int total = KH * KW * C * N;
+    hipLaunchKernelGGL(conv_flip_kernel, dim3(grid_for(total)), dim3(256), 0, stream, w, wflip, KH, KW, C, N, total);
+    DTF_CHECK_LAUNCH();
+    return 0;
+}

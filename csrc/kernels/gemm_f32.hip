@@ -55,6 +55,14 @@ struct GemmArgs {
     float* colsum;            // partial bias gradients of split 0 (may be null)
     long long colsum_split_stride;  // elements between successive splits' colsum rows
     int dbg;                  // timing-only ablation bits (DTF_GEMM_DBG); 0 in production
+    // implicit-GEMM convolution (GATHER kernels): operand A is the patch matrix of a zero-padded NHWC image that is
+    // never materialised.  Patch row m starts at element g_rowtab[m] of the image; window position w = k / g_C
+    // adds g_shift[w]; the channel k % g_C is contiguous.
+    const int* g_rowtab;      // [g_rows]
+    const int* g_shift;       // [KH*KW]
+    int g_rows;
+    int g_C;                  // channels per window position (multiple of 32 for k-contiguous A, of 4 otherwise)
+    long long g_elems;        // elements of the padded image
 };
 
 typedef unsigned int u32x4 __attribute__((vector_size(16)));
@@ -139,6 +147,97 @@ struct TileLoader {
     }
 };
 
+// Operand-A loaders of the implicit-GEMM convolution: same LDS images and the same load()/store() protocol as
+// TileLoader, but the global address of patch element (m, k) is rowtab[m] + shift[k / C] + k % C in the padded image.
+template <int ROWS, bool KC>
+struct GatherLoader;
+
+// rows = patch rows m, k contiguous inside one window position (forward, and dgrad as a convolution of dz)
+template <int ROWS>
+struct GatherLoader<ROWS, true> {
+    static constexpr int NV = ROWS * BK / 4 / 256;
+    static constexpr int LDS_FLOATS = ROWS * LDK;
+    __amdgpu_buffer_rsrc_t rsrc;
+    const int* shift;
+    int C;
+    int rb[NV];     // image offset of this thread's patch rows (-1: row past M)
+    f32x4 v[NV];
+
+    __device__ __forceinline__ void init_gather(const GemmArgs& p, int mn0, int kbeg, int tid) {
+        rsrc = make_rsrc(p.A, p.g_elems * 4);
+        shift = p.g_shift;
+        C = p.g_C;
+        __amdgpu_buffer_rsrc_t tab = make_rsrc(reinterpret_cast<const float*>(p.g_rowtab), (long long)p.g_rows * 4);
+#pragma unroll
+        for (int s = 0; s < NV; ++s) {
+            const int m = mn0 + ((tid + 256 * s) >> 3);
+            const int t = (int)__builtin_amdgcn_raw_buffer_load_b32(tab, m * 4, 0, 0);
+            rb[s] = (m < p.M) ? t : -1;
+        }
+    }
+    __device__ __forceinline__ void load(int k0, int kbeg, int k_left, int tid) {
+        const int sh = shift[k0 / C] + (k0 % C);        // uniform: a 32-deep k tile lies inside one window position
+#pragma unroll
+        for (int s = 0; s < NV; ++s) {
+            const int c = ((tid + 256 * s) & 7) * 4;
+            const bool ok = (rb[s] >= 0) && (c < k_left);
+            const unsigned off = (unsigned)(rb[s] + sh + c) * 4u;
+            const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(ok ? off : OOB), 0, 0);
+            v[s] = __builtin_bit_cast(f32x4, raw);
+        }
+    }
+    __device__ __forceinline__ void store(float* lds, int k_left, int tid) const {
+#pragma unroll
+        for (int s = 0; s < NV; ++s) {
+            const int id = tid + 256 * s;
+            *reinterpret_cast<f32x4*>(lds + (id >> 3) * LDK + (id & 7) * 4) = v[s];    // K is a multiple of BK: no tail
+        }
+    }
+};
+
+// wgrad: GEMM rows = patch columns kin (contiguous inside a window position), GEMM k = patch rows m
+template <int ROWS>
+struct GatherLoader<ROWS, false> {
+    static constexpr int NV = ROWS * BK / 4 / 256;
+    static constexpr int LDS_FLOATS = BK * (ROWS + 4);
+    __amdgpu_buffer_rsrc_t rsrc, tab;
+    int ko[NV];       // image offset of this thread's patch columns relative to the row origin (-1: past the patch)
+    int rb_next[NV];  // row origin of the NEXT tile's patch row, requested one tile ahead
+    f32x4 v[NV];
+
+    __device__ __forceinline__ void init_gather(const GemmArgs& p, int mn0, int kbeg, int tid) {
+        rsrc = make_rsrc(p.A, p.g_elems * 4);
+        tab = make_rsrc(reinterpret_cast<const float*>(p.g_rowtab), (long long)p.g_rows * 4);
+#pragma unroll
+        for (int s = 0; s < NV; ++s) {
+            const int id = tid + 256 * s;
+            const int kin = mn0 + (id % (ROWS / 4)) * 4;
+            ko[s] = (kin < p.M) ? p.g_shift[kin / p.g_C] + kin % p.g_C : -1;
+            rb_next[s] = (int)__builtin_amdgcn_raw_buffer_load_b32(tab, (kbeg + id / (ROWS / 4)) * 4, 0, 0);
+        }
+    }
+    __device__ __forceinline__ void load(int k0, int kbeg, int k_left, int tid) {
+#pragma unroll
+        for (int s = 0; s < NV; ++s) {
+            const int c = (tid + 256 * s) / (ROWS / 4);
+            const bool ok = (ko[s] >= 0) && (c < k_left);
+            const unsigned off = (unsigned)(rb_next[s] + ko[s]) * 4u;
+            const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(ok ? off : OOB), 0, 0);
+            v[s] = __builtin_bit_cast(f32x4, raw);
+        }
+#pragma unroll
+        for (int s = 0; s < NV; ++s)      // past the table the load returns 0 and the data load is masked by k_left
+            rb_next[s] = (int)__builtin_amdgcn_raw_buffer_load_b32(tab, (k0 + BK + (tid + 256 * s) / (ROWS / 4)) * 4, 0, 0);
+    }
+    __device__ __forceinline__ void store(float* lds, int k_left, int tid) const {
+#pragma unroll
+        for (int s = 0; s < NV; ++s) {
+            const int id = tid + 256 * s;
+            *reinterpret_cast<f32x4*>(lds + (id / (ROWS / 4)) * (ROWS + 4) + (id % (ROWS / 4)) * 4) = v[s];
+        }
+    }
+};
+
 // Fragment for MFMA steps t=0..3 of k-group kk: element t belongs to k = 8*kk + 4*h + t.
 template <int ROWS, bool KC>
 __device__ __forceinline__ f32x4 read_frag(const float* lds, int mn, int kk, int h) {
@@ -155,13 +254,18 @@ __device__ __forceinline__ f32x4 read_frag(const float* lds, int mn, int kk, int
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int EPI>
+template <bool GATHER, int ROWS, bool KC>
+struct PickLoader { using type = TileLoader<ROWS, KC>; };
+template <int ROWS, bool KC>
+struct PickLoader<true, ROWS, KC> { using type = GatherLoader<ROWS, KC>; };
+
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int EPI, bool GATHER = false>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
     static_assert(WM * WN == 4, "block is four waves");
     constexpr int TM = BM / WM / 32;
     constexpr int TN = BN / WN / 32;
     static_assert(TM >= 1 && TN >= 1, "wave tile must hold one 32x32 MFMA tile");
-    using LoadA = TileLoader<BM, A_KC>;
+    using LoadA = typename PickLoader<GATHER, BM, A_KC>::type;
     using LoadB = TileLoader<BN, B_KC>;
     constexpr int STAGE = LoadA::LDS_FLOATS + LoadB::LDS_FLOATS;
 
@@ -191,7 +295,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
 
     LoadA la;
     LoadB lb;
-    la.init(p.A, p.lda, m0, p.M, kbeg, p.K);
+    if constexpr (GATHER) la.init_gather(p, m0, kbeg, tid);
+    else la.init(p.A, p.lda, m0, p.M, kbeg, p.K);
     lb.init(p.B, p.ldb, n0, p.N, kbeg, p.K);
     la.load(kbeg, kbeg, kend - kbeg, tid);
     lb.load(kbeg, kbeg, kend - kbeg, tid);
@@ -306,12 +411,12 @@ inline int env_dbg() {
     return v;
 }
 
-template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int EPI>
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int EPI, bool GATHER = false>
 int launch_cfg(const GemmArgs& a, int splits, hipStream_t s) {
-    using LoadA = TileLoader<BM, A_KC>;
+    using LoadA = TileLoader<BM, A_KC>;     // the gather loaders build the same LDS images
     using LoadB = TileLoader<BN, B_KC>;
     const size_t lds = 2 * (LoadA::LDS_FLOATS + LoadB::LDS_FLOATS) * sizeof(float);
-    auto kern = gemm_f32_kernel<BM, BN, WM, WN, A_KC, B_KC, EPI>;
+    auto kern = gemm_f32_kernel<BM, BN, WM, WN, A_KC, B_KC, EPI, GATHER>;
     if (lds > 48 * 1024) {
         static bool once = false;  // per instantiation
         if (!once) {
@@ -343,6 +448,16 @@ inline int env_tile() {
         v = e ? atoi(e) : 0;
     }
     return v;
+}
+
+// Implicit-GEMM convolutions: the same tile rule over the three tiles that matter for them.
+template <bool A_KC, bool B_KC, int EPI>
+int launch_gather(const GemmArgs& a, int splits, hipStream_t s, int tile_hint = 0) {
+    if (a.N <= 32) return launch_cfg<128, 32, 4, 1, A_KC, B_KC, EPI, true>(a, splits, s);
+    if (tile_hint == 64 || a.N <= 64 || a.M <= 64) return launch_cfg<64, 64, 2, 2, A_KC, B_KC, EPI, true>(a, splits, s);
+    if (tile_hint == 128 || nblocks(a, 128, 128, splits) >= 1024)
+        return launch_cfg<128, 128, 2, 2, A_KC, B_KC, EPI, true>(a, splits, s);
+    return launch_cfg<64, 128, 2, 2, A_KC, B_KC, EPI, true>(a, splits, s);
 }
 
 template <bool A_KC, bool B_KC, int EPI>
@@ -487,6 +602,78 @@ DTF_API int dtf_dense_bwd_dw(const float* X, const float* dZ, float* dW, float* 
     const int blocks = (int)((n_total + 255) / 256);
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(1024), 0, stream, workspace, stride, eff_splits, dW,
                        kn, db, n_total);
+    DTF_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Implicit-GEMM convolution (stride 1, NHWC, zero-padded input image prepared by the caller; see conv.hip):
+// patch row m lives at rowtab[m] in the padded image, window position w at + shift[w], channels contiguous.
+
+static bool gather_ok(const int* rowtab, const int* shift, int C, int K, bool a_kc) {
+    return rowtab && shift && C > 0 && K % C == 0 && (a_kc ? C % BK == 0 : C % 4 == 0);
+}
+
+// Y[M,N] = act(patches(Xpad)[M,K] . W[K,N] + b), K = KH*KW*C
+DTF_API int dtf_conv_gemm_fwd(const float* Xpad, long long xpad_elems, const int* rowtab, const int* shift, int C,
+                              const float* W, const float* bias, float* Y, int M, int N, int K, int act,
+                              hipStream_t stream) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    if (!gather_ok(rowtab, shift, C, K, true)) return -3;
+    GemmArgs a = {};
+    a.A = Xpad; a.lda = 0; a.B = W; a.ldb = N; a.C = Y; a.ldc = N;
+    a.M = M; a.N = N; a.K = K; a.k_chunk = K;
+    a.bias = bias; a.act = act; a.keep = 1.0f;
+    a.g_rowtab = rowtab; a.g_shift = shift; a.g_rows = M; a.g_C = C; a.g_elems = xpad_elems;
+    return launch_gather<true, false, EPI_FWD>(a, 1, stream);
+}
+
+// dX[M,N] = (patches(dZpad)[M,K] . Wflip[K,N]) * act'(Yprev): the data gradient of a stride-1 convolution is the
+// convolution of the zero-padded output gradient with the spatially flipped, channel-transposed filter.
+// K = KH*KW*Cout, N = Cin.
+DTF_API int dtf_conv_gemm_dgrad(const float* dZpad, long long dzpad_elems, const int* rowtab, const int* shift, int Cout,
+                                const float* Wflip, float* dX, int M, int N, int K, const float* Yprev, int act_prev,
+                                hipStream_t stream) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    if (!gather_ok(rowtab, shift, Cout, K, true)) return -3;
+    GemmArgs a = {};
+    a.A = dZpad; a.B = Wflip; a.ldb = N; a.C = dX; a.ldc = N;
+    a.M = M; a.N = N; a.K = K; a.k_chunk = K;
+    a.yprev = Yprev; a.ldy = N; a.act = act_prev; a.scale_prev = 1.0f;
+    a.g_rowtab = rowtab; a.g_shift = shift; a.g_rows = M; a.g_C = Cout; a.g_elems = dzpad_elems;
+    return launch_gather<true, false, EPI_DX>(a, 1, stream);
+}
+
+// dW[K,N] = patches(Xpad)[M,K]^T . dZ[M,N], db = colsum(dZ); workspace as for dtf_dense_bwd_dw(M, N, K)
+DTF_API int dtf_conv_gemm_wgrad(const float* Xpad, long long xpad_elems, const int* rowtab, const int* shift, int C,
+                                const float* dZ, float* dW, float* db, int M, int N, int K, float* workspace,
+                                hipStream_t stream) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    if (!gather_ok(rowtab, shift, C, K, false)) return -3;
+    const int splits = dtf_dense_bwd_dw_splits(M, N, K);
+    const int hint = dw_tile(N, K);
+    GemmArgs a = {};
+    a.A = Xpad; a.B = dZ; a.ldb = N;
+    a.M = K; a.N = N; a.K = M; a.ldc = N;
+    a.g_rowtab = rowtab; a.g_shift = shift; a.g_rows = M; a.g_C = C; a.g_elems = xpad_elems;
+    int chunk = (M + splits - 1) / splits;
+    chunk = ((chunk + BK - 1) / BK) * BK;
+    a.k_chunk = chunk;
+    const int eff_splits = (M + chunk - 1) / chunk;
+    if (eff_splits <= 1) {
+        a.C = dW; a.c_split_stride = 0; a.colsum = db;
+        return launch_gather<false, false, EPI_DW>(a, 1, stream, hint);
+    }
+    const long long kn = (long long)K * N;
+    const long long stride = ((kn + N + 3) / 4) * 4;
+    a.C = workspace; a.c_split_stride = stride;
+    a.colsum = db ? workspace + kn : nullptr;
+    a.colsum_split_stride = stride;
+    int rc = launch_gather<false, false, EPI_DW>(a, eff_splits, stream, hint);
+    if (rc) return rc;
+    const long long n_total = db ? kn + N : kn;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((int)((n_total + 255) / 256)), dim3(1024), 0, stream, workspace, stride,
+                       eff_splits, dW, kn, db, n_total);
     DTF_CHECK_LAUNCH();
     return 0;
 }

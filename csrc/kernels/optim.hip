@@ -29,7 +29,9 @@ __device__ __forceinline__ void advance_if_last(const Advance& a) {
     if (!a.step) return;
     __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence();
+        // No fence: nothing a workgroup wrote has to be visible to the last one - only the order "every workgroup
+        // read the step, then the step changes" matters, and the ticket atomic after the barrier gives that.  (An
+        // agent-scope release here made every workgroup write back its XCD's L2: 70 us on a 1.6 M-parameter model.)
         const unsigned int t = atomicAdd(a.ticket, 1u);
         if (t == gridDim.x - 1) {
             *a.ticket = 0u;
@@ -46,9 +48,14 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ var, floa
                                                    float* __restrict__ v, const float* __restrict__ g,
                                                    long long n, float lr, float b1, float b2, float eps,
                                                    float grad_scale, const long long* step_ptr, const Advance adv) {
-    const float t = (float)(*step_ptr + 1);
-    const float b1t = powf(b1, t), b2t = powf(b2, t);
-    const float lr_t = lr * sqrtf(1.0f - b2t) / (1.0f - b1t);
+    // lr_t once per workgroup: two powf cost more than the update of the few elements a thread owns
+    __shared__ float lr_t_shared;
+    if (threadIdx.x == 0) {
+        const float t = (float)(*step_ptr + 1);
+        lr_t_shared = lr * sqrtf(1.0f - powf(b2, t)) / (1.0f - powf(b1, t));
+    }
+    __syncthreads();
+    const float lr_t = lr_t_shared;
     const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
     const long long n4 = n >> 2;
     const long long stride = (long long)gridDim.x * blockDim.x;

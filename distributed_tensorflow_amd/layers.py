@@ -267,8 +267,12 @@ class Conv2D(Layer):
 
     Executed as patch matrix x filter matrix on the MFMA GEMM kernels: the kernel variable viewed as
     ``[kh*kw*cin, cout]`` is the GEMM's B operand as stored, the GEMM output ``[B*OH*OW, cout]`` is the NHWC result as
-    stored, and bias / activation / bias-gradient ride in the GEMM epilogues exactly as for ``Dense``.  The patch
-    matrix is kept from forward to backward (wgrad reads it), then reused as the buffer of the patch gradients.
+    stored, and bias / activation / bias-gradient ride in the GEMM epilogues exactly as for ``Dense``.  On the GPU
+    with stride 1 and channel counts that are multiples of 32 the patch matrix is implicit: the GEMM's operand loader
+    gathers patch rows from a zero-padded copy of the image (forward and weight gradient), and the data gradient is
+    the same kind of convolution over the zero-padded output gradient with the flipped filter.  Other shapes
+    materialise the patch matrix, keep it from forward to backward (wgrad reads it) and reuse it as the buffer of
+    the patch gradients.
     """
 
     prefix = "conv2d"
@@ -296,6 +300,8 @@ class Conv2D(Layer):
         self._buf = _Buffers()
         self._ws = None
         self._x = self._y = self._cols = None
+        self._geo = {}
+        self._used_implicit = False
 
     def compute_output_shape(self, input_shape):
         if len(input_shape) != 3:
@@ -328,23 +334,59 @@ class Conv2D(Layer):
         cols = self._buf.get("cols", (B * OH * OW, kh * kw * C), x.device)
         return F.im2col(x, kh, kw, self.strides, self.padding, out=cols)
 
+    # ---- implicit-GEMM path (GPU, stride 1, 32-channel multiples): the GEMM kernels gather patch rows straight from
+    #      a zero-padded copy of the image, so no [B*OH*OW, kh*kw*cin] matrix ever exists in HBM
+    def _implicit(self, x) -> bool:
+        if not x.is_cuda or self.kernel_size == (1, 1):
+            return False
+        need_dgrad = self.need_input_grad
+        return F.conv_implicit_supported(x.shape[3], self.filters, self.strides, need_dgrad)
+
+    def _geometry(self, x):
+        """Per-batch-size tables and buffers of the implicit path (built once, reused every step)."""
+        B, H, W, C = x.shape
+        key = (B, str(x.device))
+        g = self._geo.get(key)
+        if g is None:
+            kh, kw = self.kernel_size
+            OH, OW, pt, pl, pb, pr = F.conv_geometry(H, W, kh, kw, self.strides, self.padding)
+            Hp, Wp = H + pt + pb, W + pl + pr
+            g = {"pt": pt, "pl": pl, "Hp": Hp, "Wp": Wp, "xpad": torch.empty((B, Hp, Wp, C), dtype=torch.float32, device=x.device)}
+            g["rowtab"], g["shift"] = F.conv_tables(B, OH, OW, Hp, Wp, kh, kw, C, x.device)
+            if self.need_input_grad:
+                N = self.filters
+                g["top"], g["left"], g["Hq"], g["Wq"] = kh - 1 - pt, kw - 1 - pl, H + kh - 1, W + kw - 1
+                g["dzpad"] = torch.empty((B, g["Hq"], g["Wq"], N), dtype=torch.float32, device=x.device)
+                g["rowtab_d"], g["shift_d"] = F.conv_tables(B, H, W, g["Hq"], g["Wq"], kh, kw, N, x.device)
+                g["wflip"] = torch.empty((kh * kw * N, C), dtype=torch.float32, device=x.device)
+            self._geo[key] = g
+        return g
+
     def forward(self, x, training):
         if x.dim() != 4:
             raise ValueError("Conv2D expects NHWC input, got shape %s" % (tuple(x.shape),))
         x = x.contiguous()
         B = x.shape[0]
         OH, OW, Fo = self.output_shape
-        cols = self._patches(x)
         y = self._buf.get("y", (B * OH * OW, Fo), x.device)
-        F.dense_forward(cols, self.kernel.tensor.view(-1, Fo), self.bias.tensor if self.bias is not None else None,
-                        self.act, out=y)
+        bias = self.bias.tensor if self.bias is not None else None
+        self._used_implicit = self._implicit(x)
+        if self._used_implicit:
+            g = self._geometry(x)
+            F.conv_pad(x, g["pt"], g["pl"], g["Hp"], g["Wp"], out=g["xpad"])
+            F.conv_gemm_forward(g["xpad"], g["rowtab"], g["shift"], self.kernel.tensor.view(-1, Fo), bias, self.act, y)
+            cols = None
+        else:
+            cols = self._patches(x)
+            F.dense_forward(cols, self.kernel.tensor.view(-1, Fo), bias, self.act, out=y)
         self._x, self._cols, self._y = x, cols, y
         return y.view(B, OH, OW, Fo)
 
     def backward(self, dy):
         x, cols, y = self._x, self._cols, self._y
         M, Fo = y.shape
-        K = cols.shape[1]
+        kh, kw = self.kernel_size
+        K = kh * kw * x.shape[3]
         dy2 = dy.reshape(M, Fo)
         if self.grad_is_dz or self.act == ACT_NONE:
             dz = dy2 if dy2.is_contiguous() else dy2.contiguous()
@@ -356,11 +398,24 @@ class Conv2D(Layer):
                 self._ws = (M, torch.empty(max(need, 1), dtype=torch.float32, device=x.device))
             else:
                 self._ws = (M, self._ws[1])
-        F.dense_backward_dw(cols, dz, self.kernel.grad.view(-1, Fo), self.bias.grad if self.bias is not None else None,
-                            workspace=self._ws[1])
+        dw2d = self.kernel.grad.view(-1, Fo)
+        db = self.bias.grad if self.bias is not None else None
+        if self._used_implicit:
+            g = self._geometry(x)
+            F.conv_gemm_wgrad(g["xpad"], g["rowtab"], g["shift"], dz, dw2d, db, self._ws[1])
+            if not self.need_input_grad:
+                return None
+            B, H, W, C = x.shape
+            OH, OW, _ = self.output_shape
+            F.conv_pad(dz.view(B, OH, OW, Fo), g["top"], g["left"], g["Hq"], g["Wq"], out=g["dzpad"])
+            F.conv_flip_weights(self.kernel.tensor, out=g["wflip"])
+            dx = self._buf.get("dx", (B * H * W, C), x.device)
+            F.conv_gemm_dgrad(g["dzpad"], g["rowtab_d"], g["shift_d"], g["wflip"], dx,
+                              yprev=x.view(-1, C) if self.fuse_prev_relu else None)
+            return dx.view(x.shape)
+        F.dense_backward_dw(cols, dz, dw2d, db, workspace=self._ws[1])
         if not self.need_input_grad:
             return None
-        kh, kw = self.kernel_size
         if (kh, kw) == (1, 1) and self.strides == (1, 1):
             dx = self._buf.get("dx", (M, K), x.device)
             F.dense_backward_dx(dz, self.kernel.tensor.view(-1, Fo), x.reshape(M, K) if self.fuse_prev_relu else None,

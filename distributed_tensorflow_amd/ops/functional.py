@@ -570,3 +570,84 @@ def mlp_tail(h1, w2, b2, w3, b3, labels, dz1, dw2, db2, dw3, db3, workspace, kee
         nv.ptr(dw3), nv.ptr(db3), nv.ptr(workspace), int(workspace.numel()), int(M), int(H1), int(H2), int(C),
         float(keep2), int(seed2) & _M32, nv.ptr(step), float(scale1), float(grad_scale), nv.ptr(stats), nv.stream_ptr())
     nv.check(rc, "dtf_mlp_tail")
+
+
+# ----------------------------------------------------------------------------- implicit-GEMM convolution (GPU, stride 1)
+def conv_implicit_supported(c_in: int, c_out: int, strides, need_dgrad: bool = True) -> bool:
+    """The GEMM kernels can gather patch rows straight from a zero-padded image (no patch matrix in HBM) when the
+    stride is 1 and a 32-deep k tile lies inside one window position: ``c_in % 32 == 0`` (and ``c_out % 32 == 0``
+    for the data gradient, which is a convolution over the output gradient)."""
+    return tuple(strides) == (1, 1) and c_in % 32 == 0 and (not need_dgrad or c_out % 32 == 0) and nv.kernels_available() \
+        and hasattr(nv.kernels(), "dtf_conv_gemm_fwd")
+
+
+def conv_pad(x, pt: int, pl: int, Hp: int, Wp: int, out=None):
+    """Zero-padded copy ``[B, Hp, Wp, C]`` of an NHWC tensor with the image at offset (pt, pl)."""
+    B, H, W, C = x.shape
+    if out is None:
+        out = torch.empty((B, Hp, Wp, C), dtype=torch.float32, device=x.device)
+    nv.require_f32_contig(x, out)
+    rc = nv.kernels().dtf_conv_pad(nv.ptr(x), nv.ptr(out), B, H, W, C, pt, pl, Hp, Wp, nv.stream_ptr())
+    nv.check(rc, "dtf_conv_pad")
+    return out
+
+
+def conv_tables(B: int, OH: int, OW: int, Hp: int, Wp: int, KH: int, KW: int, C: int, device):
+    """``(rowtab, shift)``: element offset of every output pixel's patch origin in the padded image, and of every
+    window position relative to that origin."""
+    rowtab = torch.empty(B * OH * OW, dtype=torch.int32, device=device)
+    rc = nv.kernels().dtf_conv_rowtab(nv.ptr(rowtab), B, OH, OW, Hp, Wp, C, nv.stream_ptr())
+    nv.check(rc, "dtf_conv_rowtab")
+    kh = torch.arange(KH, dtype=torch.int32).view(KH, 1)
+    kw = torch.arange(KW, dtype=torch.int32).view(1, KW)
+    shift = ((kh * Wp + kw) * C).reshape(-1).contiguous().to(device)
+    return rowtab, shift
+
+
+def conv_flip_weights(w, out=None):
+    """``[KH, KW, C, N]`` filter -> ``[(KH*KW*N), C]`` matrix of the data-gradient convolution (spatially flipped,
+    channels transposed)."""
+    KH, KW, C, N = w.shape
+    if out is None:
+        out = torch.empty((KH * KW * N, C), dtype=torch.float32, device=w.device)
+    nv.require_f32_contig(w, out)
+    rc = nv.kernels().dtf_conv_flip_weights(nv.ptr(w), nv.ptr(out), KH, KW, C, N, nv.stream_ptr())
+    nv.check(rc, "dtf_conv_flip_weights")
+    return out
+
+
+def conv_gemm_forward(xpad, rowtab, shift, w2d, bias, act, out):
+    """``out[M, N] = act(patches(xpad) @ w2d + bias)`` with the patches gathered inside the GEMM."""
+    K, N = w2d.shape
+    M = rowtab.numel()
+    C = xpad.shape[-1]
+    nv.require_f32_contig(xpad, w2d, bias, out)
+    rc = nv.kernels().dtf_conv_gemm_fwd(nv.ptr(xpad), xpad.numel(), nv.ptr(rowtab), nv.ptr(shift), C, nv.ptr(w2d), nv.ptr(bias),
+                                        nv.ptr(out), M, N, K, int(act), nv.stream_ptr())
+    nv.check(rc, "dtf_conv_gemm_fwd")
+    return out
+
+
+def conv_gemm_wgrad(xpad, rowtab, shift, dz, dw2d, db, workspace):
+    """``dw2d[K, N] = patches(xpad)^T @ dz``, ``db = colsum(dz)``."""
+    K, N = dw2d.shape
+    M = rowtab.numel()
+    nv.require_f32_contig(xpad, dz, dw2d, db, workspace)
+    need = dense_dw_workspace_floats(M, N, K)
+    if workspace is None or workspace.numel() < max(need, 1):
+        raise ValueError("conv wgrad workspace needs %d floats" % need)
+    rc = nv.kernels().dtf_conv_gemm_wgrad(nv.ptr(xpad), xpad.numel(), nv.ptr(rowtab), nv.ptr(shift), xpad.shape[-1], nv.ptr(dz),
+                                          nv.ptr(dw2d), nv.ptr(db), M, N, K, nv.ptr(workspace), nv.stream_ptr())
+    nv.check(rc, "dtf_conv_gemm_wgrad")
+
+
+def conv_gemm_dgrad(dzpad, rowtab, shift, wflip, dx, yprev=None):
+    """``dx[M, C] = patches(dzpad) @ wflip`` (optionally times the ReLU gradient of ``yprev``)."""
+    K, C = wflip.shape
+    M = rowtab.numel()
+    nv.require_f32_contig(dzpad, wflip, dx, yprev)
+    rc = nv.kernels().dtf_conv_gemm_dgrad(nv.ptr(dzpad), dzpad.numel(), nv.ptr(rowtab), nv.ptr(shift), dzpad.shape[-1],
+                                          nv.ptr(wflip), nv.ptr(dx), M, C, K, nv.ptr(yprev),
+                                          ACT_RELU if yprev is not None else ACT_NONE, nv.stream_ptr())
+    nv.check(rc, "dtf_conv_gemm_dgrad")
+    return dx

@@ -85,3 +85,81 @@ def test_mnist_cnn_learns(gpu_device):
     h = m.fit(x.view(-1, 28, 28, 1), y, epochs=3, batch_size=128, validation_data=(xt.view(-1, 28, 28, 1), yt), verbose=0)
     assert h.history["loss"][-1] < h.history["loss"][0]
     assert h.history["val_acc"][-1] > 0.5
+
+
+@pytest.mark.parametrize("g", [
+    dict(B=4, H=14, W=14, C=32, N=64, KH=5, KW=5, padding="same"),
+    dict(B=3, H=9, W=11, C=64, N=32, KH=3, KW=3, padding="valid"),
+    dict(B=2, H=8, W=8, C=32, N=96, KH=2, KW=3, padding="same"),
+    dict(B=70, H=14, W=14, C=32, N=64, KH=5, KW=5, padding="same"),
+])
+def test_implicit_gemm_conv_matches_patch_matrix_path(gpu_device, g):
+    """Forward, weight gradient and data gradient with the patches gathered inside the GEMM against the same
+    products on a materialised patch matrix (and, through that, torch conv2d)."""
+    gen = torch.Generator().manual_seed(4)
+    B, H, W, C, N, KH, KW = (g[k] for k in ("B", "H", "W", "C", "N", "KH", "KW"))
+    assert F.conv_implicit_supported(C, N, (1, 1))
+    x = torch.randn(B, H, W, C, generator=gen).to(gpu_device)
+    w = (torch.randn(KH, KW, C, N, generator=gen) * 0.1).to(gpu_device)
+    b = torch.randn(N, generator=gen).to(gpu_device)
+    OH, OW, pt, pl, pb, pr = F.conv_geometry(H, W, KH, KW, (1, 1), g["padding"])
+    M, K = B * OH * OW, KH * KW * C
+    # reference: explicit patch matrix
+    cols = F.im2col(x, KH, KW, (1, 1), g["padding"])
+    y_ref = F.dense_forward(cols, w.view(K, N), b, F.ACT_RELU)
+    dz = torch.randn(M, N, generator=gen).to(gpu_device)
+    dw_ref, db_ref = torch.empty(K, N, device=gpu_device), torch.empty(N, device=gpu_device)
+    F.dense_backward_dw(cols, dz, dw_ref, db_ref)
+    yprev = torch.randn(B, H, W, C, generator=gen).to(gpu_device)
+    dx_ref = F.col2im(F.dense_backward_dx(dz, w.view(K, N)), x.shape, KH, KW, (1, 1), g["padding"], yprev=yprev)
+    # implicit
+    Hp, Wp = H + pt + pb, W + pl + pr
+    xpad = F.conv_pad(x, pt, pl, Hp, Wp)
+    assert torch.equal(xpad[:, pt:pt + H, pl:pl + W, :], x) and float(xpad.sum()) == pytest.approx(float(x.sum()), rel=1e-4)
+    rowtab, shift = F.conv_tables(B, OH, OW, Hp, Wp, KH, KW, C, gpu_device)
+    y = F.conv_gemm_forward(xpad, rowtab, shift, w.view(K, N), b, F.ACT_RELU, torch.empty(M, N, device=gpu_device))
+    torch.testing.assert_close(y, y_ref, rtol=1e-4, atol=1e-4)
+    dw, db = torch.full((K, N), float("nan"), device=gpu_device), torch.full((N,), float("nan"), device=gpu_device)
+    ws = torch.empty(max(F.dense_dw_workspace_floats(M, N, K), 1), device=gpu_device)
+    F.conv_gemm_wgrad(xpad, rowtab, shift, dz, dw, db, ws)
+    torch.testing.assert_close(dw, dw_ref, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(db, db_ref, rtol=1e-3, atol=1e-3)
+    top, left = KH - 1 - pt, KW - 1 - pl
+    Hq, Wq = H + KH - 1, W + KW - 1
+    dzpad = F.conv_pad(dz.view(B, OH, OW, N), top, left, Hq, Wq)
+    rowtab_d, shift_d = F.conv_tables(B, H, W, Hq, Wq, KH, KW, N, gpu_device)
+    wflip = F.conv_flip_weights(w)
+    dx = F.conv_gemm_dgrad(dzpad, rowtab_d, shift_d, wflip, torch.empty(B * H * W, C, device=gpu_device), yprev=yprev.view(-1, C))
+    torch.testing.assert_close(dx.view(B, H, W, C), dx_ref, rtol=1e-3, atol=1e-3)
+
+
+def test_cnn_with_implicit_convs_matches_autograd(gpu_device):
+    """A model whose convolutions take the implicit-GEMM path (32-channel multiples, stride 1): every gradient against
+    PyTorch autograd on the CPU."""
+    from distributed_tensorflow_amd.layers import Conv2D, Dense, Flatten, MaxPooling2D
+    from distributed_tensorflow_amd.models import Sequential
+
+    def build():
+        return Sequential([
+            Conv2D(32, (3, 3), padding="same", activation="relu", input_shape=(8, 8, 32)),
+            Conv2D(64, (3, 3), padding="valid", activation="relu"),
+            MaxPooling2D((2, 2)),
+            Conv2D(32, (2, 2), padding="same", activation="relu"),
+            Flatten(),
+            Dense(5, activation="softmax"),
+        ])
+    m = build()
+    m.compile(loss="sparse_categorical_crossentropy", optimizer="sgd", metrics=["accuracy"], device=gpu_device, seed=3)
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(6, 8, 8, 32, generator=gen)
+    y = torch.randint(0, 5, (6,), generator=gen)
+    m.compute_gradients(x.to(gpu_device), y.to(gpu_device))
+    convs = [l for l in m.layers if isinstance(l, Conv2D)]
+    assert [c._used_implicit for c in convs] == [True, True, True]
+    host = build()
+    host.compile(loss="sparse_categorical_crossentropy", optimizer="sgd", device="cpu", seed=3)
+    host.store.flat.copy_(m.store.flat.cpu())
+    ref_loss, params = _autograd_reference(host, x, y)
+    assert m.read_stats()["loss"] == pytest.approx(ref_loss, rel=1e-4)
+    for v, p in zip(m.store.trainable, params):
+        torch.testing.assert_close(v.grad.cpu(), p.grad, rtol=2e-3, atol=2e-5, msg=v.name)
