@@ -166,9 +166,15 @@ def main():
     def step(i):
         run(i, 1)
 
+    def barrier():
+        if dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[dev.index])
+        else:
+            dist.barrier()       # DTF_COMM_BACKEND=gloo: ranks time-sharing one GPU (rehearsal on a one-GPU box)
+
     def fence():
         if multi:
-            dist.barrier(device_ids=[dev.index])
+            barrier()
         torch.cuda.synchronize()
 
     run(0, args.warmup)
@@ -218,7 +224,7 @@ def main():
         }
         print(json.dumps(out), flush=True)
     if multi:
-        dist.barrier(device_ids=[dev.index])
+        barrier()
     if dist.is_initialized():
         dist.destroy_process_group()
 

@@ -225,7 +225,8 @@ class ParameterServerService:
             return
         from .comm import init_process_group
         host, port = self.server.rendezvous_address()
-        backend = "nccl" if self.device.type == "cuda" else "gloo"
+        from .comm import pick_backend
+        backend = pick_backend(self.device)
         init_process_group(backend, rank=self.rank, world_size=self.server.world_size, master_addr=host,
                            master_port=port, device=self.device if backend == "nccl" else None)
         self._owns_group = True
@@ -432,7 +433,8 @@ class AsyncPSStrategy:
         # data plane (after the layout is out: ps tasks join the process group once they have it)
         if not dist.is_initialized():
             host, port = srv.rendezvous_address()
-            backend = "nccl" if dev.type == "cuda" else "gloo"
+            from .comm import pick_backend
+            backend = pick_backend(dev)
             world = self.num_workers if self.colocated else srv.world_size
             rank = self.worker_index if self.colocated else srv.rank
             init_process_group(backend, rank=rank, world_size=world, master_addr=host, master_port=port,

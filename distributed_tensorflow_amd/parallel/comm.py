@@ -27,6 +27,18 @@ def env_local_rank() -> int:
     return int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
 
 
+def pick_backend(device=None) -> str:
+    """``nccl`` (RCCL) for GPU tensors, ``gloo`` for CPU.  ``DTF_COMM_BACKEND=gloo`` forces gloo for GPU tensors too:
+    RCCL refuses two ranks on one device, so several ranks time-sharing a single GPU (the one-GPU test box) talk
+    through gloo while every kernel still runs on the GPU."""
+    forced = os.environ.get("DTF_COMM_BACKEND")
+    if forced:
+        return forced
+    if device is not None:
+        return "nccl" if torch.device(device).type == "cuda" else "gloo"
+    return "nccl" if torch.cuda.is_available() else "gloo"
+
+
 def init_process_group(backend: Optional[str] = None, rank: Optional[int] = None, world_size: Optional[int] = None,
                        master_addr: Optional[str] = None, master_port: Optional[int] = None,
                        timeout_s: float = 600.0, device: Optional[torch.device] = None):
@@ -35,8 +47,8 @@ def init_process_group(backend: Optional[str] = None, rank: Optional[int] = None
         return dist.group.WORLD
     rank = env_rank() if rank is None else rank
     world_size = env_world_size() if world_size is None else world_size
-    if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend is None or os.environ.get("DTF_COMM_BACKEND"):
+        backend = pick_backend(device)
     addr = master_addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
     port = master_port or int(os.environ.get("MASTER_PORT", "29500"))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC is what the host driver supports

@@ -1,0 +1,74 @@
+"""Several ranks time-sharing the one GPU of the test box: every kernel runs on the GPU, the ranks talk through gloo
+(RCCL refuses two ranks on one device).  This rehearses the multi-process paths - the reference's 1 ps + 2 workers
+launch and the torchrun launch of bench.py - with the HIP kernels in the loop."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from distributed_tensorflow_amd.saver import latest_checkpoint
+
+from .test_example_cluster import SCRIPT, _ports
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WAIT = int(os.environ.get("DTF_TEST_WAIT", "100"))     # per process; a stuck cluster fails with its logs instead of hanging
+
+
+def _env(extra=None):
+    env = dict(os.environ)
+    for k in ("JOB_NAME", "TASK_INDEX", "PS_HOSTS", "WORKER_HOSTS", "RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    env["DTF_COMM_BACKEND"] = "gloo"
+    env["OMP_NUM_THREADS"] = "2"
+    env.update(extra or {})
+    return env
+
+
+@pytest.mark.parametrize("mode", ["async", "sync"])
+def test_one_ps_two_workers_on_one_gpu(tmp_path, mode):
+    ps_port, w0, w1, rdv = _ports(4)
+    hosts = {"PS_HOSTS": "127.0.0.1:%d" % ps_port, "WORKER_HOSTS": "127.0.0.1:%d,127.0.0.1:%d" % (w0, w1),
+             "DTF_RENDEZVOUS_PORT": str(rdv)}
+    args = [sys.executable, SCRIPT, "--log_dir", str(tmp_path), "--last_step", "200", "--seed", "5"] + \
+        (["--sync"] if mode == "sync" else ["--max_staleness", "3"])
+    procs, logs = {}, {}
+    try:
+        for job, idx in (("ps", 0), ("worker", 0), ("worker", 1)):
+            logs[(job, idx)] = open(str(tmp_path / ("%s%d.log" % (job, idx))), "w+")
+            procs[(job, idx)] = subprocess.Popen(args, env=_env(dict(hosts, JOB_NAME=job, TASK_INDEX=str(idx))),
+                                                 stdout=logs[(job, idx)], stderr=subprocess.STDOUT)
+        for key in (("worker", 0), ("worker", 1), ("ps", 0)):
+            try:
+                rc = procs[key].wait(timeout=WAIT)
+            except subprocess.TimeoutExpired:
+                rc = None
+            logs[key].seek(0)
+            text = logs[key].read()
+            assert rc == 0, "%s%d rc=%s\n%s" % (key[0], key[1], rc, text[-3000:])
+            if key[0] == "worker":
+                assert "Training complete!" in text
+    finally:
+        for p in procs.values():
+            if p.poll() is None:
+                p.kill()
+        for f in logs.values():
+            f.close()
+    ck = latest_checkpoint(str(tmp_path))
+    assert ck is not None and 200 <= int(ck.rsplit("-", 1)[1]) <= 204
+
+
+def test_bench_two_ranks_share_the_gpu():
+    """bench.py launched exactly as the multi-GPU driver launches it (torch.distributed.run, 2 ranks)."""
+    port = _ports(1)[0]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+           "--batch-per-gpu", "4096"]
+    out = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=WAIT, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8192 and d["config"]["parallelism"] == "dp2"
+    assert d["value"] > 0 and d["steps"] == 6
