@@ -58,6 +58,7 @@ def define_flags():
     flags.DEFINE_boolean("sync", False, "synchronous replicas instead of the asynchronous parameter server")
     flags.DEFINE_integer("max_staleness", -1, "asynchronous mode: bound on worker clock skew (-1 = unbounded)")
     flags.DEFINE_integer("last_step", int(epochs * (train_set_size / train_batch_size)), "global step to stop at")
+    flags.DEFINE_float("save_checkpoint_secs", 600.0, "seconds between the chief's periodic checkpoints (TF default 600)")
     flags.DEFINE_integer("seed", -1, "data / initialisation seed (-1 = unseeded, like the reference)")
     return flags.FLAGS
 
@@ -122,7 +123,8 @@ def main():
 
     hooks = [tf.train.StopAtStepHook(last_step=FLAGS.last_step)]
     with tf.train.MonitoredTrainingSession(master=target, is_chief=(FLAGS.task_index == 0),
-                                           checkpoint_dir=FLAGS.log_dir, hooks=hooks) as sess:
+                                           checkpoint_dir=FLAGS.log_dir, hooks=hooks,
+                                           save_checkpoint_secs=FLAGS.save_checkpoint_secs) as sess:
         writer.add_graph(sess.graph)
         epoch = 0
         while not sess.should_stop():
