@@ -290,8 +290,20 @@ class Server:
             while True:
                 time.sleep(3600)
         from .parallel.async_ps import ParameterServerService
+        detector = None
+        if os.environ.get("DTF_HEARTBEAT", "1") != "0":
+            # a parameter server blocked in a transfer with a dead worker would wait forever: the detector ends the
+            # process instead, so that the launcher can restart the cluster from the last checkpoint
+            from .failure import detector_for_server
+            detector = detector_for_server(self, interval_s=float(os.environ.get("DTF_HEARTBEAT_SECS", "0.5")),
+                                           max_age_s=float(os.environ.get("DTF_HEARTBEAT_MAX_AGE_SECS", "5")),
+                                           abort_after_s=float(os.environ.get("DTF_HEARTBEAT_ABORT_SECS", "10")))
+            if detector is not None:
+                detector.start()
         self._ps_service = ParameterServerService(self)
         self._ps_service.serve()
+        if detector is not None:
+            detector.stop(clean=True)
 
     def shutdown_parameter_servers(self):
         """Ask every ps task to leave ``join()`` (for clusters whose strategy does not use them)."""

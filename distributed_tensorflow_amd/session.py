@@ -315,6 +315,7 @@ class MonitoredSession:
         if self.is_chief and self.checkpoint_dir:
             latest = saver_mod.latest_checkpoint(self.checkpoint_dir)
             if latest:
+                print("INFO: Restoring parameters from %s" % latest, flush=True)
                 self.engine.restore_checkpoint(self._saver(), latest)
                 restored = True
         if self.is_chief and not restored and self.scaffold.init_fn is not None and first:
@@ -418,6 +419,12 @@ def MonitoredTrainingSession(master: str = "", is_chief: bool = True, checkpoint
             all_hooks.append(CheckpointSaverHook(checkpoint_dir, save_secs=save_checkpoint_secs,
                                                  saver=scaffold.saver if scaffold else None))
     all_hooks.extend(hooks or [])
+    from .cluster import current_server
+    srv = current_server()
+    if master and srv is not None and srv.world_size > 1 and master == srv.target \
+            and os.environ.get("DTF_HEARTBEAT", "1") != "0":
+        from .failure import HeartbeatHook
+        all_hooks.append(HeartbeatHook(srv))      # a lost task surfaces as ClusterLostError instead of a hang
     return MonitoredSession(engine, is_chief=is_chief, master=master, checkpoint_dir=checkpoint_dir, hooks=all_hooks,
                             scaffold=scaffold, max_recoveries=max_recoveries,
                             stop_grace_period_secs=stop_grace_period_secs)

@@ -40,6 +40,7 @@ def test_kill_then_resume_from_latest_checkpoint(tmp_path):
     out = subprocess.run(args + ["--last_step", str(target)], env=_env(), capture_output=True, text=True, timeout=240)
     assert out.returncode == 0, out.stderr[-3000:]
     assert "Training complete!" in out.stdout
+    assert "Restoring parameters from %s" % ck in out.stdout
     final = latest_checkpoint(log_dir)
     assert final.endswith("model.ckpt-%d" % target)           # it ran exactly to the absolute step, not 'target' more steps
     with BundleReader(final) as r:
