@@ -11,6 +11,8 @@ from distributed_tensorflow_amd.ops import functional as F  # noqa: E402
 dev = torch.device("cuda")
 M = int(os.environ.get("M", 32768))
 shapes = [(M, 784, 128), (M, 128, 128), (M, 128, 10)]
+if os.environ.get("SHAPE"):                      # SHAPE=m,k,n times that single product
+    shapes = [tuple(int(v) for v in os.environ["SHAPE"].split(","))]
 rounds = 20
 
 

@@ -25,13 +25,19 @@ a.record()
 F.dense_forward(x, w, b, 1, out=y)
 e.record()
 torch.cuda.synchronize()
-t = y.view(M // BM, BM, N // BN, BN)[:, 0, :, :2].reshape(-1, 2).double().cpu()
+t = y.view(M // BM, BM, N // BN, BN)[:, 0, :, :5].reshape(-1, 5).double().cpu()
 cyc, ticks = t[:, 0], t[:, 1]
 us = ticks / 100.0
 kit = (K + 31) // 32
 print("kernel %.1f us; blocks %d" % (a.elapsed_time(e) * 1000, cyc.numel()))
 print("loop us  : mean %.1f min %.1f max %.1f" % (us.mean(), us.min(), us.max()))
 print("loop cyc : mean %.0f min %.0f max %.0f  (memtime units)" % (cyc.mean(), cyc.min(), cyc.max()))
+print("loop only cyc (before the epilogue): mean %.0f min %.0f max %.0f" % (t[:, 2].mean(), t[:, 2].min(), t[:, 2].max()))
+entry, exit_ = t[:, 3], t[:, 4]
+e0 = entry.min()
+print("block entry (us after the first block): mean %.1f max %.1f; exit: min %.1f mean %.1f max %.1f; entry->loop start mean %.1f us"
+      % ((entry - e0).mean() / 100, (entry - e0).max() / 100, (exit_ - e0).min() / 100, (exit_ - e0).mean() / 100,
+         (exit_ - e0).max() / 100, ((exit_ - entry) - ticks).mean() / 100))
 print("memtime units per us: %.1f" % (cyc.sum() / us.sum()))
 print("per k-iter: %.2f us -> at 64 MFMA/wave/iter: %.1f ns per MFMA" % (us.mean() / kit, 1000 * us.mean() / kit / 64))
 hist = torch.histc(us.float(), bins=8, min=float(us.min()), max=float(us.max()) + 1e-3)

@@ -24,7 +24,9 @@
 // conflict-free.
 #include "common.h"
 
+#include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -54,7 +56,7 @@ struct GemmArgs {
     // wgrad extras
     float* colsum;            // partial bias gradients of split 0 (may be null)
     long long colsum_split_stride;  // elements between successive splits' colsum rows
-    int dbg;                  // timing-only ablation bits (DTF_GEMM_DBG); 0 in production
+    int dbg;                  // DTF_GEMM_DBG bit 8: every block stamps its main-loop time over its first outputs; 0 in production
     // implicit-GEMM convolution (GATHER kernels): operand A is the patch matrix of a zero-padded NHWC image that is
     // never materialised.  Patch row m starts at element g_rowtab[m] of the image; window position w = k / g_C
     // adds g_shift[w]; the channel k % g_C is contiguous.
@@ -85,6 +87,7 @@ struct TileLoader {
     __amdgpu_buffer_rsrc_t rsrc;
     int ld;
     int mn_left;   // valid rows/cols of the M/N dimension from this block's origin
+    unsigned voff[NV];   // byte offset of this thread's vectors inside the first k tile; OOB if its row/column is outside
     f32x4 v[NV];
 
     // base points at element (mn0, kbeg) of the operand; rows_total/k_total bound the allocation
@@ -98,36 +101,53 @@ struct TileLoader {
             // rows = k index: base + kbeg*ld + mn0 ; buffer ends after row k_total-1
             rsrc = make_rsrc(base + (long long)kbeg * ld + mn0, (((long long)(k_total - kbeg)) * ld - mn0) * 4);
         }
+        const int tid = threadIdx.x;
+#pragma unroll
+        for (int s = 0; s < NV; ++s) {
+            const int id = tid + 256 * s;
+            if (KC) {
+                const int r = id >> 3, c = (id & 7) * 4;
+                voff[s] = (r < mn_left) ? ((unsigned)r * (unsigned)ld + (unsigned)c) * 4u : OOB;
+            } else {
+                const int c = id / (ROWS / 4), r = (id % (ROWS / 4)) * 4;
+                voff[s] = (r < mn_left) ? ((unsigned)c * (unsigned)ld + (unsigned)r) * 4u : OOB;
+            }
+        }
     }
 
     // Issue the tile's loads (k0: absolute k of the tile start; k_left = kend - k0).  Nothing here
     // consumes the data, so the wait lands in store(), after the MFMAs of the previous tile.
+    // A full tile costs one add and one select per vector: the per-thread part of the address is fixed, the tile
+    // adds a uniform offset, and rows / columns outside the operand were given the out-of-range offset once.
     __device__ __forceinline__ void load(int k0, int kbeg, int k_left, int tid) {
+        const unsigned koff = KC ? (unsigned)k0 * 4u : (unsigned)(k0 - kbeg) * (unsigned)ld * 4u;
+        const bool full = k_left >= BK;
 #pragma unroll
         for (int s = 0; s < NV; ++s) {
             const int id = tid + 256 * s;
-            unsigned off;
-            bool ok;
-            if (KC) {
-                const int r = id >> 3;            // mn index
-                const int c = (id & 7) * 4;       // k index
-                off = ((unsigned)r * (unsigned)ld + (unsigned)(k0 + c)) * 4u;
-                ok = (r < mn_left) && (c < k_left);
-            } else {
-                const int c = id / (ROWS / 4);         // k index
-                const int r = (id % (ROWS / 4)) * 4;   // mn index
-                off = ((unsigned)(k0 - kbeg + c) * (unsigned)ld + (unsigned)r) * 4u;
-                ok = (c < k_left) && (r < mn_left);
-            }
+            const int c = KC ? (id & 7) * 4 : id / (ROWS / 4);       // k index inside the tile
+            const bool ok = (voff[s] != OOB) && (full || c < k_left);
             // whole-vector bit_cast only: indexing the builtin's result element-wise makes hipcc
             // (ROCm 7.2) emit a single-dword load
-            const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(ok ? off : OOB), 0, 0);
+            const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(ok ? voff[s] + koff : OOB), 0, 0);
             v[s] = __builtin_bit_cast(f32x4, raw);
         }
     }
 
-    // Zero the elements past the K (or M/N) tail of a partially valid vector and write the LDS image.
+    // Write the LDS image.  Only a vector that straddles the end of K (k-contiguous tiles) or of the M/N range
+    // needs its tail elements zeroed; that is decided per tile with a uniform test.
     __device__ __forceinline__ void store(float* lds, int k_left, int tid) const {
+        const bool plain = KC ? (k_left >= BK) : (mn_left >= ROWS);
+        if (plain) {
+#pragma unroll
+            for (int s = 0; s < NV; ++s) {
+                const int id = tid + 256 * s;
+                const int off = KC ? (id >> 3) * LDK + (id & 7) * 4
+                                   : (id / (ROWS / 4)) * (ROWS + 4) + (id % (ROWS / 4)) * 4;
+                *reinterpret_cast<f32x4*>(lds + off) = v[s];
+            }
+            return;
+        }
 #pragma unroll
         for (int s = 0; s < NV; ++s) {
             const int id = tid + 256 * s;
@@ -270,6 +290,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
     constexpr int STAGE = LoadA::LDS_FLOATS + LoadB::LDS_FLOATS;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];   // two stages of [A tile | B tile]
+    unsigned long long dbg_entry = 0;
+    if (p.dbg & 8) dbg_entry = __builtin_amdgcn_s_memrealtime();
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -306,51 +328,84 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
 
     unsigned long long dbg_t0 = 0, dbg_r0 = 0;
     if (p.dbg & 8) { dbg_t0 = __builtin_amdgcn_s_memtime(); dbg_r0 = __builtin_amdgcn_s_memrealtime(); }
+    // Main loop.  The fragments of k-group kk+1 are requested from LDS after the first TM*TN MFMAs of k-group kk and
+    // before its other 3*TM*TN (two fragment register sets; scheduling fences keep the compiler from sinking the
+    // reads next to their use): a read issued right before its consumer leaves the matrix pipe idle for the LDS
+    // latency once per k-group.  In the last k-group of a tile the same slot holds the store of the next tile, the
+    // barrier and the request for that tile's first fragments, so these are covered by 3*TM*TN MFMAs as well.
     int stage = 0;
+    f32x4 fa[2][TM], fb[2][TN];
+    {
+        const float* As = smem;
+        const float* Bs = As + LoadA::LDS_FLOATS;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[0][i] = read_frag<BM, A_KC>(As, (wm * TM + i) * 32 + li, 0, h);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[0][j] = read_frag<BN, B_KC>(Bs, (wn * TN + j) * 32 + li, 0, h);
+    }
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         const bool more = (k0 + BK) < kend;
         const float* As = smem + stage * STAGE;
         const float* Bs = As + LoadA::LDS_FLOATS;
-        if (more && !(p.dbg & 1)) {
+        if (more && !(p.dbg & 1)) {     // bit 1 (diagnostic): no global loads after the first tile
             la.load(k0 + BK, kbeg, kend - k0 - BK, tid);
             lb.load(k0 + BK, kbeg, kend - k0 - BK, tid);
         }
-        // All fragments of the 32-deep tile are fetched up front (16*(TM+TN) registers): the LDS
-        // reads issue back to back and the MFMAs drain them with counted waits, instead of every
-        // MFMA pair paying the latency of a read issued just before it.
-        f32x4 a[BK / 8][TM], b[BK / 8][TN];
 #pragma unroll
         for (int kk = 0; kk < BK / 8; ++kk) {
+            constexpr int LAST = BK / 8 - 1;
+            const int cur = kk & 1, nxt = cur ^ 1;
+            // step t = 0 first: whatever wait precedes it only concerns reads issued a whole k-group ago
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[kk][i] = read_frag<BM, A_KC>(As, (wm * TM + i) * 32 + li, kk, h);
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[kk][j] = read_frag<BN, B_KC>(Bs, (wn * TN + j) * 32 + li, kk, h);
-        }
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][0], fb[cur][j][0], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kk < LAST) {
 #pragma unroll
-        for (int kk = 0; kk < BK / 8; ++kk)
+                for (int i = 0; i < TM; ++i) fa[nxt][i] = read_frag<BM, A_KC>(As, (wm * TM + i) * 32 + li, kk + 1, h);
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+                for (int j = 0; j < TN; ++j) fb[nxt][j] = read_frag<BN, B_KC>(Bs, (wn * TN + j) * 32 + li, kk + 1, h);
+            } else {
+                if (EPI == EPI_DW) {
+                    if (do_colsum && tid < BN) {
+                        // B tile is n-contiguous here: Bs[k][n].  Rows past kend were staged as zeros.
+#pragma unroll 8
+                        for (int k = 0; k < BK; ++k) csum += Bs[k * (BN + 4) + tid];
+                    }
+                }
+                // Unconditional barrier and reads (after the last tile they fetch stale data nobody uses): one path
+                // through here lets the compiler count outstanding LDS operations exactly instead of draining them.
+                float* nx = smem + (stage ^ 1) * STAGE;
+                if (more) {
+                    la.store(nx, kend - k0 - BK, tid);
+                    lb.store(nx + LoadA::LDS_FLOATS, kend - k0 - BK, tid);
+                }
+                __syncthreads();
+                const float* An = nx;
+                const float* Bn = nx + LoadA::LDS_FLOATS;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[nxt][i] = read_frag<BM, A_KC>(An, (wm * TM + i) * 32 + li, 0, h);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[nxt][j] = read_frag<BN, B_KC>(Bn, (wn * TN + j) * 32 + li, 0, h);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 1; t < 4; ++t)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][i][t], b[kk][j][t], acc[i][j], 0, 0, 0);
-        if (EPI == EPI_DW) {
-            if (do_colsum && tid < BN) {
-                // B tile is n-contiguous here: Bs[k][n].  Rows past kend were staged as zeros.
-#pragma unroll 8
-                for (int k = 0; k < BK; ++k) csum += Bs[k * (BN + 4) + tid];
-            }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][t], fb[cur][j][t], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (more && !(p.dbg & 2)) {
-            float* nxt = smem + (stage ^ 1) * STAGE;
-            la.store(nxt, kend - k0 - BK, tid);
-            lb.store(nxt + LoadA::LDS_FLOATS, kend - k0 - BK, tid);
-        }
-        if (!(p.dbg & 4)) __syncthreads();
         stage ^= 1;
     }
 
+    unsigned long long dbg_t1 = 0;
+    if (p.dbg & 8) dbg_t1 = __builtin_amdgcn_s_memtime();
     // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     float* C = p.C + (long long)blockIdx.z * p.c_split_stride;
     uint32_t key = 0;
@@ -360,41 +415,68 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
         key = dtf_dropout_key(p.seed, p.step_ptr);
         inv_keep = 1.0f / p.keep;
     }
+    // A tile that lies entirely inside C (all of them except the last row / column of tiles) skips the per-element
+    // bounds tests: with them the epilogue is several thousand instructions and costs about a tenth of a short-K GEMM.
+    const float relu_floor = (p.act == ACT_RELU) ? 0.f : -INFINITY;
+    auto write_tile = [&](auto checked, auto simple) {
+        constexpr bool CHECK = decltype(checked)::value;
+        constexpr bool SIMPLE = decltype(simple)::value;   // forward: bias and ReLU / identity only; dgrad: ReLU mask or none
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+        for (int i = 0; i < TM; ++i) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + (wn * TN + j) * 32 + li;
-            if (col >= p.N) continue;
-            float bv = 0.f;
-            if (EPI == EPI_FWD && p.bias) bv = p.bias[col];
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + (wn * TN + j) * 32 + li;
+                if (CHECK && col >= p.N) continue;
+                float bv = 0.f;
+                if (EPI == EPI_FWD && p.bias) bv = p.bias[col];
+                const int row0 = m0 + (wm * TM + i) * 32 + 4 * h;
+                float* Cp = C + (long long)row0 * p.ldc + col;
+                const float* Yp = (EPI == EPI_DX && p.yprev) ? p.yprev + (long long)row0 * p.ldy + col : nullptr;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (row >= p.M) continue;
-                float v = acc[i][j][r];
-                if (EPI == EPI_FWD) {
-                    v += bv;
-                    if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
-                    else if (p.act == ACT_SIGMOID) v = dtf_sigmoid(v);
-                    if (drop) {
-                        const float u = dtf_uniform(key, (unsigned long long)row * (unsigned)p.N + col);
-                        v = (u < p.keep) ? v * inv_keep : 0.f;
+                for (int r = 0; r < 16; ++r) {
+                    const int dr = (r & 3) + 8 * (r >> 2);
+                    if (CHECK && row0 + dr >= p.M) continue;
+                    float v = acc[i][j][r];
+                    if (EPI == EPI_FWD) {
+                        v += bv;
+                        if (SIMPLE) {
+                            v = fmaxf(v, relu_floor);
+                        } else {
+                            if (p.act == ACT_SIGMOID) v = dtf_sigmoid(v);
+                            else v = fmaxf(v, relu_floor);
+                            if (drop) {
+                                const float u = dtf_uniform(key, (unsigned long long)(row0 + dr) * (unsigned)p.N + col);
+                                v = (u < p.keep) ? v * inv_keep : 0.f;
+                            }
+                        }
+                    } else if (EPI == EPI_DX) {
+                        if (SIMPLE) {
+                            if (Yp) v = (Yp[(long long)dr * p.ldy] > 0.f) ? v * p.scale_prev : 0.f;
+                        } else if (Yp) {
+                            const float y = Yp[(long long)dr * p.ldy];
+                            if (p.act == ACT_RELU) v = (y > 0.f) ? v * p.scale_prev : 0.f;
+                            else if (p.act == ACT_SIGMOID) v = v * y * (1.0f - y);
+                        }
                     }
-                } else if (EPI == EPI_DX) {
-                    if (p.yprev) {
-                        const float y = p.yprev[(long long)row * p.ldy + col];
-                        if (p.act == ACT_RELU) v = (y > 0.f) ? v * p.scale_prev : 0.f;
-                        else if (p.act == ACT_SIGMOID) v = v * y * (1.0f - y);
-                    }
+                    Cp[(long long)dr * p.ldc] = v;
                 }
-                C[(long long)row * p.ldc + col] = v;
             }
         }
+    };
+    const bool simple = (EPI == EPI_FWD) ? (!drop && p.act != ACT_SIGMOID)
+                                         : (EPI == EPI_DX ? (p.yprev == nullptr || p.act == ACT_RELU) : true);
+    if (m0 + BM <= p.M && n0 + BN <= p.N) {
+        if (simple) write_tile(std::false_type{}, std::true_type{});
+        else write_tile(std::false_type{}, std::false_type{});
+    } else {
+        write_tile(std::true_type{}, std::false_type{});
     }
     if ((p.dbg & 8) && tid == 0) {   // timing-only diagnostic: loop cycles and 100 MHz ticks into the tile's first row
         C[(long long)m0 * p.ldc + n0] = (float)(__builtin_amdgcn_s_memtime() - dbg_t0);
         C[(long long)m0 * p.ldc + n0 + 1] = (float)(__builtin_amdgcn_s_memrealtime() - dbg_r0);
+        C[(long long)m0 * p.ldc + n0 + 2] = (float)(dbg_t1 - dbg_t0);
+        C[(long long)m0 * p.ldc + n0 + 3] = (float)(dbg_entry & 0xFFFFF);                         // block entry, 10 ns ticks
+        C[(long long)m0 * p.ldc + n0 + 4] = (float)(__builtin_amdgcn_s_memrealtime() & 0xFFFFF);  // block exit
     }
     if (EPI == EPI_DW) {
         if (do_colsum && tid < BN && (n0 + tid) < p.N)
@@ -434,11 +516,46 @@ int launch_cfg(const GemmArgs& a, int splits, hipStream_t s) {
     return 0;
 }
 
-// Tile choice: the largest tile that still gives every CU about two co-resident blocks (a block
-// that sits in its LDS-store / barrier phase is covered by the other block's MFMAs); N <= 32
-// uses the narrow tile so thin output layers (10 / 32 columns) do not pay for 128 columns.
+// Tile choice by a small cost model.  A CU holds as many blocks as its 160 KB of LDS allow; resident blocks share
+// the four matrix pipes, so a "round" of resident blocks takes (blocks per CU) x (one block's MFMA cycles), and a
+// grid that does not fill its last round evenly pays for that round as if it were as full as its fullest CU.
+// N <= 32 uses the narrow tile so thin output layers (10 / 32 columns) do not pay for 128 columns.
 inline long long nblocks(const GemmArgs& a, int bm, int bn, int splits) {
     return (long long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn) * splits;
+}
+
+inline size_t tile_lds_bytes(int bm, int bn, bool a_kc, bool b_kc) {
+    const size_t fa = a_kc ? (size_t)bm * LDK : (size_t)BK * (bm + 4);
+    const size_t fb = b_kc ? (size_t)bn * LDK : (size_t)BK * (bn + 4);
+    return 2 * (fa + fb) * sizeof(float);
+}
+
+constexpr double BLOCK_OVERHEAD_CYCLES = 6000.0;   // first-tile latency + epilogue of one block (measured ~3 us)
+
+inline double tile_cost(long long M, long long N, long long kc, int splits, int bm, int bn, bool a_kc, bool b_kc) {
+    const long long nb = ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * splits;
+    long long res = (long long)((160 * 1024) / tile_lds_bytes(bm, bn, a_kc, b_kc));
+    if (res > 4) res = 4;
+    const long long slots = 256 * res;
+    const long long full = nb / slots, rem = nb % slots;
+    const long long seq = full * res + (rem + 255) / 256;          // blocks the busiest CU runs one after another
+    double c = (double)seq * ((double)bm * bn * (double)kc / 128.0 + BLOCK_OVERHEAD_CYCLES);
+    if (full == 0 && rem <= 256) c *= 1.2;     // a lone block per CU cannot hide its LDS-store and barrier phases
+    if (bm * bn <= 64 * 64) c *= 1.1;          // 32x32 wave tiles: twice the LDS fragment traffic per MFMA (measured)
+    return c;
+}
+
+// 128 (=128x128), 6428 (=64x128) or 64 (=64x64)
+inline int pick_tile(const GemmArgs& a, int splits, bool a_kc, bool b_kc) {
+    if (a.N <= 64 || a.M <= 64) return 64;
+    const long long kc = a.k_chunk < a.K ? a.k_chunk : a.K;
+    int best = 128;
+    double cost = tile_cost(a.M, a.N, kc, splits, 128, 128, a_kc, b_kc);
+    const double c1 = tile_cost(a.M, a.N, kc, splits, 64, 128, a_kc, b_kc);
+    if (c1 < cost) { cost = c1; best = 6428; }
+    const double c2 = tile_cost(a.M, a.N, kc, splits, 64, 64, a_kc, b_kc);
+    if (c2 < cost) { cost = c2; best = 64; }
+    return best;
 }
 
 inline int env_tile() {
@@ -450,27 +567,27 @@ inline int env_tile() {
     return v;
 }
 
-// Implicit-GEMM convolutions: the same tile rule over the three tiles that matter for them.
+template <bool A_KC, bool B_KC, int EPI, bool GATHER>
+int launch_tiled(const GemmArgs& a, int splits, hipStream_t s, int tile_hint) {
+    if (a.N <= 32) return launch_cfg<128, 32, 4, 1, A_KC, B_KC, EPI, GATHER>(a, splits, s);
+    int t = tile_hint;
+    if (a.N <= 64 || a.M <= 64) t = 64;
+    else if (env_tile()) t = env_tile();
+    else if (t != 64 && t != 128 && t != 6428) t = pick_tile(a, splits, A_KC, B_KC);
+    if (t == 128) return launch_cfg<128, 128, 2, 2, A_KC, B_KC, EPI, GATHER>(a, splits, s);
+    if (t == 6428) return launch_cfg<64, 128, 2, 2, A_KC, B_KC, EPI, GATHER>(a, splits, s);
+    return launch_cfg<64, 64, 2, 2, A_KC, B_KC, EPI, GATHER>(a, splits, s);
+}
+
+// Implicit-GEMM convolutions use the same rule.
 template <bool A_KC, bool B_KC, int EPI>
 int launch_gather(const GemmArgs& a, int splits, hipStream_t s, int tile_hint = 0) {
-    if (a.N <= 32) return launch_cfg<128, 32, 4, 1, A_KC, B_KC, EPI, true>(a, splits, s);
-    if (tile_hint == 64 || a.N <= 64 || a.M <= 64) return launch_cfg<64, 64, 2, 2, A_KC, B_KC, EPI, true>(a, splits, s);
-    if (tile_hint == 128 || nblocks(a, 128, 128, splits) >= 1024)
-        return launch_cfg<128, 128, 2, 2, A_KC, B_KC, EPI, true>(a, splits, s);
-    return launch_cfg<64, 128, 2, 2, A_KC, B_KC, EPI, true>(a, splits, s);
+    return launch_tiled<A_KC, B_KC, EPI, true>(a, splits, s, tile_hint);
 }
 
 template <bool A_KC, bool B_KC, int EPI>
 int launch_gemm(const GemmArgs& a, int splits, hipStream_t s, int tile_hint = 0) {
-    if (a.N > 32 && env_tile() == 6428) return launch_cfg<64, 128, 2, 2, A_KC, B_KC, EPI>(a, splits, s);
-    if (a.N > 32 && env_tile() == 128) return launch_cfg<128, 128, 2, 2, A_KC, B_KC, EPI>(a, splits, s);
-    if (a.N > 32 && env_tile() == 64) return launch_cfg<64, 64, 2, 2, A_KC, B_KC, EPI>(a, splits, s);
-    if (a.N <= 32) return launch_cfg<128, 32, 4, 1, A_KC, B_KC, EPI>(a, splits, s);
-    if (tile_hint == 64 || a.N <= 64 || a.M <= 64) return launch_cfg<64, 64, 2, 2, A_KC, B_KC, EPI>(a, splits, s);
-    if (tile_hint == 128) return launch_cfg<128, 128, 2, 2, A_KC, B_KC, EPI>(a, splits, s);
-    if (nblocks(a, 128, 128, splits) >= 1024) return launch_cfg<128, 128, 2, 2, A_KC, B_KC, EPI>(a, splits, s);
-    if (nblocks(a, 64, 128, splits) >= 384) return launch_cfg<64, 128, 2, 2, A_KC, B_KC, EPI>(a, splits, s);
-    return launch_cfg<64, 64, 2, 2, A_KC, B_KC, EPI>(a, splits, s);
+    return launch_tiled<A_KC, B_KC, EPI, false>(a, splits, s, tile_hint);
 }
 
 // out[i] = sum_s slabs[s * slab_stride + i].  A 1024-thread block covers 64 float4 columns with 16
@@ -552,31 +669,57 @@ DTF_API int dtf_dense_bwd_dx(const float* dZ, const float* W, float* dX, int M, 
     return launch_gemm<true, true, EPI_DX>(a, 1, stream);
 }
 
-// wgrad tiling: outputs of at most 128x128 use 64x64 tiles (fewer batch splits for the same
-// number of blocks => less slab traffic); larger ones 128x128 tiles.  About two blocks per CU.
-static int dw_tile(int N, int K) {
-    if (N <= 32) return 32;
-    return ((long long)K * N <= 128 * 128) ? 64 : 128;
+// wgrad plan: tile and number of batch splits are chosen together.  For every tile the split count that fills the
+// CUs' resident-block slots once is priced with the same model as above plus the slab traffic of the split-batch
+// reduction (each split writes, and the reducer reads, a K x N slab).
+struct DwPlan { int tile; int splits; };
+
+static DwPlan dw_plan(int M, int N, int K) {
+    if (const char* e = getenv("DTF_DW_PLAN")) {     // tuning aid: "tile,splits"
+        int t = 0, sp = 0;
+        if (sscanf(e, "%d,%d", &t, &sp) == 2 && sp >= 1) return {t, sp};
+    }
+    int max_by_m = (M + 8 * BK - 1) / (8 * BK);      // at least 256 rows of batch per split
+    if (max_by_m < 1) max_by_m = 1;
+    if (N <= 32) {
+        const int tiles = ((K + 127) / 128) * ((N + 31) / 32);
+        int want = 512 / tiles;
+        if (want < 1) want = 1;
+        return {32, want < max_by_m ? want : max_by_m};
+    }
+    const int cand[3][3] = {{128, 128, 128}, {64, 128, 6428}, {64, 64, 64}};
+    DwPlan best = {64, 1};
+    double best_cost = -1.0;
+    for (int c = 0; c < 3; ++c) {
+        const int bm = cand[c][0], bn = cand[c][1];
+        if ((K <= 64 || N <= 64) && cand[c][2] != 64) continue;
+        const long long tiles = (long long)((K + bm - 1) / bm) * ((N + bn - 1) / bn);
+        long long res = (long long)((160 * 1024) / tile_lds_bytes(bm, bn, false, false));
+        if (res > 4) res = 4;
+        long long want = (256 * res) / tiles;
+        if (want < 1) want = 1;
+        int sp = (int)(want < max_by_m ? want : max_by_m);
+        int chunk = (((M + sp - 1) / sp + BK - 1) / BK) * BK;
+        sp = (M + chunk - 1) / chunk;
+        double cost = tile_cost(K, N, chunk, sp, bm, bn, false, false);
+        if (sp > 1) cost += 2.0 * sp * (double)K * N * 4.0 * 0.0007;     // slab bytes at ~3 TB/s, in 2.1 GHz cycles
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = {cand[c][2], sp}; }
+    }
+    return best;
 }
+
+static int dw_tile(int N, int K, int M) { return dw_plan(M, N, K).tile; }
 
 // Number of batch splits the wgrad kernel uses for (M,N,K); the workspace must hold
 // splits * round_up(K*N + N, 4) floats when splits > 1.
-DTF_API int dtf_dense_bwd_dw_splits(int M, int N, int K) {
-    const int t = dw_tile(N, K);
-    const int tiles = (t == 32) ? ((K + 127) / 128) * ((N + 31) / 32) : ((K + t - 1) / t) * ((N + t - 1) / t);
-    int want = 512 / tiles;                           // floor: at most two blocks per CU
-    if (want < 1) want = 1;
-    int max_by_m = (M + 8 * BK - 1) / (8 * BK);      // at least 256 rows of batch per split
-    int s = want < max_by_m ? want : max_by_m;
-    return s < 1 ? 1 : s;
-}
+DTF_API int dtf_dense_bwd_dw_splits(int M, int N, int K) { return dw_plan(M, N, K).splits; }
 
 // dW[K,N] = X[M,K]^T . dZ[M,N];  db[N] = sum_m dZ[m,:]  (db may be null).
 DTF_API int dtf_dense_bwd_dw(const float* X, const float* dZ, float* dW, float* db, int M, int N, int K,
                              float* workspace, hipStream_t stream) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     const int splits = dtf_dense_bwd_dw_splits(M, N, K);
-    const int hint = dw_tile(N, K);
+    const int hint = dw_tile(N, K, M);
     GemmArgs a = {};
     a.A = X; a.lda = K;       // A(i=kin, k=m) = X[m*K + kin] -> i-contiguous
     a.B = dZ; a.ldb = N;
@@ -651,7 +794,7 @@ DTF_API int dtf_conv_gemm_wgrad(const float* Xpad, long long xpad_elems, const i
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     if (!gather_ok(rowtab, shift, C, K, false)) return -3;
     const int splits = dtf_dense_bwd_dw_splits(M, N, K);
-    const int hint = dw_tile(N, K);
+    const int hint = dw_tile(N, K, M);
     GemmArgs a = {};
     a.A = Xpad; a.B = dZ; a.ldb = N;
     a.M = K; a.N = N; a.K = M; a.ldc = N;
