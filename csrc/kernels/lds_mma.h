@@ -44,15 +44,17 @@ struct LdsStage {
 //   B_KC: B[n][k] row-major (k contiguous)   else B[k][n]
 // Lane (li = lane & 31, h = lane >> 5) feeds row/column li; within a group of 8 k-values half h takes k = 4h..4h+3,
 // so a k-contiguous operand is one 16-byte LDS read per group (row strides with stride/4 odd are conflict-free).
+// The fragments of k-group g+1 are requested after the first MFMA of group g and before its other three (two
+// register sets; the scheduling fences keep the compiler from moving the reads next to their consumers): a read
+// issued right before the MFMA that needs it idles the matrix pipe for the LDS latency in every group.
 template <bool A_KC, bool B_KC, int K>
 __device__ __forceinline__ void lds_tile_mma(f32x16& acc, const float* A, int lda, int m0, const float* B, int ldb, int n0,
                                              int lane) {
+    static_assert(K % 8 == 0, "k extent is a multiple of the 8-deep fragment group");
     const int li = lane & 31, h = lane >> 5;
     const float* pa = A_KC ? A + (m0 + li) * lda + 4 * h : A + (4 * h) * lda + m0 + li;
     const float* pb = B_KC ? B + (n0 + li) * ldb + 4 * h : B + (4 * h) * ldb + n0 + li;
-#pragma unroll 4
-    for (int kk = 0; kk < K; kk += 8) {
-        f32x4 a, b;
+    auto read = [&](int kk, f32x4& a, f32x4& b) {
         if (A_KC) {
             a = *reinterpret_cast<const f32x4*>(pa + kk);
         } else {
@@ -65,9 +67,21 @@ __device__ __forceinline__ void lds_tile_mma(f32x16& acc, const float* A, int ld
             const float* q = pb + kk * ldb;
             b[0] = q[0]; b[1] = q[ldb]; b[2] = q[2 * ldb]; b[3] = q[3 * ldb];
         }
+    };
+    f32x4 a[2], b[2];
+    read(0, a[0], b[0]);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], acc, 0, 0, 0);
+    for (int g = 0; g < K / 8; ++g) {
+        const int cur = g & 1;
+        __builtin_amdgcn_sched_barrier(0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][0], b[cur][0], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + 1 < K / 8) read((g + 1) * 8, a[cur ^ 1], b[cur ^ 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 1; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][t], b[cur][t], acc, 0, 0, 0);
     }
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 __device__ __forceinline__ void lds_zero(f32x16& a) {

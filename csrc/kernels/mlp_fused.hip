@@ -22,6 +22,7 @@
 //     layer-wise kernels, so both paths draw identical masks; all sums have a fixed order.
 // Variables are read with sc1 (L2-served) loads: the CU re-reads values it stored one step earlier.
 #include "common.h"
+#include "lds_mma.h"
 
 namespace {
 
@@ -103,33 +104,11 @@ struct Stage {
     }
 };
 
-// One 32x32 output tile: acc += sum_k A(m,k) B(k,n), both operands in LDS.
-//   A_KC: A[m][k] row-major (k contiguous)   else A[k][m]
-//   B_KC: B[n][k] row-major (k contiguous)   else B[k][n]
+// One 32x32 output tile: acc += sum_k A(m,k) B(k,n), both operands in LDS (software-pipelined fragment reads).
 template <bool A_KC, bool B_KC, int K>
 __device__ __forceinline__ void tile_mma(f32x16& acc, const float* A, int lda, int m0, const float* B, int ldb, int n0,
                                          int lane) {
-    const int li = lane & 31, h = lane >> 5;
-    const float* pa = A_KC ? A + (m0 + li) * lda + 4 * h : A + (4 * h) * lda + m0 + li;
-    const float* pb = B_KC ? B + (n0 + li) * ldb + 4 * h : B + (4 * h) * ldb + n0 + li;
-#pragma unroll 4
-    for (int kk = 0; kk < K; kk += 8) {
-        f32x4 a, b;
-        if (A_KC) {
-            a = *reinterpret_cast<const f32x4*>(pa + kk);
-        } else {
-            const float* q = pa + kk * lda;
-            a[0] = q[0]; a[1] = q[lda]; a[2] = q[2 * lda]; a[3] = q[3 * lda];
-        }
-        if (B_KC) {
-            b = *reinterpret_cast<const f32x4*>(pb + kk);
-        } else {
-            const float* q = pb + kk * ldb;
-            b[0] = q[0]; b[1] = q[ldb]; b[2] = q[2 * ldb]; b[3] = q[3 * ldb];
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], acc, 0, 0, 0);
-    }
+    lds_tile_mma<A_KC, B_KC, K>(acc, A, lda, m0, B, ldb, n0, lane);
 }
 
 __device__ __forceinline__ void zero(f32x16& a) {
