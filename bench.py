@@ -196,7 +196,10 @@ def main():
         xt, yt = make(8192, 99)
         test_acc = model.evaluate(xt, yt, batch_size=8192)[1]
 
+    staleness = None
     if args.mode == "async":
+        # observed staleness of this rank's pushes: owner updates applied between its pull and its push
+        staleness = {str(k): v for k, v in sorted(strategy.staleness_hist.items())}
         strategy.worker_done()
         strategy.cp0.barrier("bench_done", world, timeout_s=300)
         if rank == 0:
@@ -220,7 +223,9 @@ def main():
             "config": {"model": args.model, "global_batch": global_batch, "batch_per_gpu": B, "seq_len": None,
                        "parallelism": ("dp%d" if args.mode == "sync" else "async-ps%d") % world, "params": model.store.num_params,
                        "optimizer": "adam", "hip_graph": bool(use_graph), "fused_step_kernel": plan is not None,
-                       "train_loss": logs.get("loss"), "train_acc": logs.get("acc"), "test_acc": test_acc},
+                       "train_loss": logs.get("loss"), "train_acc": logs.get("acc"), "test_acc": test_acc,
+                       **({"max_staleness": args.max_staleness, "staleness_histogram_rank0": staleness}
+                          if staleness is not None else {})},
         }
         print(json.dumps(out), flush=True)
     if multi:

@@ -1,7 +1,8 @@
 // Multi-threaded stress of the host runtime, meant to be built with -fsanitize=thread:
 //   * control plane: one server, several client threads hammering counters, queues, clocks, barriers, blocking GETs
 //     and heartbeats concurrently (thread-per-connection server, shared maps behind one mutex);
-//   * event writer: several producer threads against the writer's queue thread.
+//   * event writer: several producer threads against the writer's queue thread;
+//   * input pipeline: producer threads filling a slot ring against a consumer that releases slots late.
 // Prints "STRESS_OK" and exits 0 when every invariant held; ThreadSanitizer reports races on stderr.
 #include <atomic>
 #include <cstdint>
@@ -31,6 +32,12 @@ void* dtf_events_open(const char* logdir, const char* suffix, int max_queue, dou
 int dtf_events_add_scalars(void* h, int n, const char* const* tags, const float* values, int64_t step, double wall_time);
 int dtf_events_flush(void* h);
 int dtf_events_close(void* h);
+void* dtf_pipe_create(const void* x, const void* y, int64_t rows, int64_t x_row_bytes, int64_t y_row_bytes, int64_t batch,
+                      int shuffle, uint64_t seed, int drop_last, int depth, int threads, void** x_slots, void** y_slots);
+int64_t dtf_pipe_start_epoch(void* h, int64_t epoch);
+int dtf_pipe_next(void* h, int64_t* slot, int64_t* rows);
+void dtf_pipe_release(void* h, int64_t slot);
+void dtf_pipe_destroy(void* h);
 }
 
 static std::atomic<int> failures{0};
@@ -109,6 +116,38 @@ int main(int argc, char** argv) {
     }
     for (auto& th : threads) th.join();
     CHECK(dtf_events_close(w) == 0);
+
+    // input pipeline: 4 producers, 3 slots, a consumer that releases late, one epoch abandoned half way
+    {
+        const int64_t rows = 1003, batch = 32, depth = 3;
+        std::vector<int64_t> x(rows), y(rows);
+        for (int64_t i = 0; i < rows; ++i) { x[i] = i; y[i] = 7 * i; }
+        std::vector<std::vector<int64_t>> xs(depth, std::vector<int64_t>(batch)), ys(depth, std::vector<int64_t>(batch));
+        std::vector<void*> xp, yp;
+        for (int i = 0; i < depth; ++i) { xp.push_back(xs[i].data()); yp.push_back(ys[i].data()); }
+        void* pipe = dtf_pipe_create(x.data(), y.data(), rows, 8, 8, batch, 1, 11, 0, (int)depth, 4, xp.data(), yp.data());
+        CHECK(pipe != nullptr);
+        for (int epoch = 0; pipe && epoch < 4; ++epoch) {
+            const int64_t nb = dtf_pipe_start_epoch(pipe, epoch);
+            CHECK(nb == (rows + batch - 1) / batch);
+            std::vector<int> seen(rows, 0);
+            int64_t slot = 0, n = 0, prev = -1, got = 0;
+            while (dtf_pipe_next(pipe, &slot, &n) == 0) {
+                for (int64_t i = 0; i < n; ++i) {
+                    const int64_t r = xs[slot][i];
+                    CHECK(r >= 0 && r < rows && ys[slot][i] == 7 * r);
+                    if (r >= 0 && r < rows) ++seen[r];
+                }
+                if (prev >= 0) dtf_pipe_release(pipe, prev);     // hold one slot while the next is read
+                prev = slot;
+                if (epoch == 2 && ++got == nb / 2) break;          // walk away in the middle of an epoch
+            }
+            if (prev >= 0) dtf_pipe_release(pipe, prev);
+            if (epoch != 2)
+                for (int64_t i = 0; i < rows; ++i) CHECK(seen[i] == 1);
+        }
+        if (pipe) dtf_pipe_destroy(pipe);
+    }
 
     if (failures.load() == 0) std::puts("STRESS_OK");
     return failures.load() == 0 ? 0 : 1;

@@ -118,7 +118,8 @@ def build_runtime_stress(sanitizer: str = "thread", verbose: bool = True) -> Pat
     out_dir.mkdir(parents=True, exist_ok=True)
     out = out_dir / ("stress_runtime_%s" % sanitizer)
     sources = [CSRC / "runtime" / "tests" / "stress_runtime.cc", CSRC / "runtime" / "control_plane.cc",
-               CSRC / "runtime" / "events_writer.cc", CSRC / "runtime" / "crc32c.cc"]
+               CSRC / "runtime" / "events_writer.cc", CSRC / "runtime" / "crc32c.cc",
+               CSRC / "runtime" / "input_pipeline.cc"]
     stamp = out_dir / (out.name + ".stamp")
     want = _digest(sources + sorted((CSRC / "runtime").glob("*.h")))
     if out.exists() and stamp.exists() and stamp.read_text() == want:

@@ -462,8 +462,12 @@ class Sequential:
     # ------------------------------------------------------------------ fit
     def fit(self, x, y, epochs: int = 1, batch_size: int = 32, validation_data=None, callbacks=None,
             shuffle: bool = True, verbose: int = 1, steps_per_graph: int = 0, initial_epoch: int = 0,
-            fused: Optional[bool] = None):
+            fused: Optional[bool] = None, stream_from_host: bool = False, shuffle_seed: int = 0):
         """Keras ``fit``.  Data is moved to the device once; each epoch reshuffles on the device.
+
+        ``stream_from_host=True`` keeps ``x`` / ``y`` in host memory instead (data sets larger than HBM): C++ worker
+        threads gather each epoch's shuffled batches into pinned buffers and a copy stream moves them to the device
+        ahead of the step that consumes them (``input_pipeline.HostPipeline``).
 
         ``steps_per_graph > 0`` (GPU only) replays that many consecutive steps from one
         captured hipGraph; 0 launches every kernel eagerly.  ``fused`` (default: automatic) selects the
@@ -471,6 +475,9 @@ class Sequential:
         layer-by-layer path.
         """
         self._check_compiled()
+        if stream_from_host:
+            return self._fit_streamed(x, y, epochs, batch_size, validation_data, callbacks, shuffle, verbose,
+                                      initial_epoch, shuffle_seed)
         xd, yd = _as_tensor(x, self.device), _as_tensor(y, self.device)
         n = xd.shape[0]
         val = None
@@ -544,6 +551,44 @@ class Sequential:
             cl.call("on_epoch_end", epoch, logs)
         cl.call("on_train_end", None)
         return history
+
+    def _fit_streamed(self, x, y, epochs, batch_size, validation_data, callbacks, shuffle, verbose, initial_epoch,
+                      shuffle_seed):
+        from ..input_pipeline import HostPipeline
+        pipe = HostPipeline(x, y, batch_size=batch_size, shuffle=shuffle, seed=shuffle_seed, device=self.device)
+        try:
+            n = pipe.rows
+            steps = int(math.ceil(n / float(batch_size)))
+            val = None
+            if validation_data is not None:
+                val = (_as_tensor(validation_data[0], self.device), _as_tensor(validation_data[1], self.device))
+            params = {"epochs": epochs, "batch_size": batch_size, "steps": steps, "samples": n,
+                      "metrics": ["loss"] + (["acc"] if self.metrics else [])}
+            history = cb.History()
+            cbs = [history] + ([cb.ProgbarLogger()] if verbose else []) + list(callbacks or [])
+            cl = cb.CallbackList(cbs, self, params)
+            self.stop_training = False
+            cl.call("on_train_begin", None)
+            for epoch in range(initial_epoch, epochs):
+                if self.stop_training:
+                    break
+                cl.call("on_epoch_begin", epoch, None)
+                self.stats.zero_()
+                for s, (xb, yb) in enumerate(pipe.batches(epoch)):
+                    self.train_step(xb, yb)
+                    if cl.wants_batch_logs:
+                        cl.call("on_batch_end", s, {})
+                logs = self.read_stats()
+                if val is not None:
+                    ev = self.evaluate(val[0], val[1], batch_size=max(batch_size, 1))
+                    logs["val_loss"] = ev[0]
+                    if len(ev) > 1:
+                        logs["val_acc"] = ev[1]
+                cl.call("on_epoch_end", epoch, logs)
+            cl.call("on_train_end", None)
+            return history
+        finally:
+            pipe.close()
 
     # ------------------------------------------------------------------ misc
     def summary(self) -> str:
