@@ -37,10 +37,13 @@ __device__ __forceinline__ uint32_t dtf_dropout_key(uint32_t seed, const long lo
 }
 
 // Counter-based uniform in [0,1): a pure function of (key, element index), so the
-// backward pass can regenerate a mask instead of storing it.
+// backward pass can regenerate a mask instead of storing it.  One avalanche round over
+// index * golden-ratio + key (the key is itself a two-round mix of seed and step): 32-bit
+// integer multiplies issue at quarter rate, and a layer's dropout decisions are made inside
+// GEMM epilogues where vector issue slots are what limits the kernel, so the hash is kept to three.
 __device__ __forceinline__ float dtf_uniform(uint32_t key, unsigned long long idx) {
-    uint32_t r = dtf_mix32((uint32_t)idx * 0x9E3779B1u + key);
-    r = dtf_mix32(r ^ ((uint32_t)(idx >> 32) + 0x632BE5ABu) ^ (key >> 7));
+    const uint32_t hi = (uint32_t)(idx >> 32);
+    const uint32_t r = dtf_mix32(((uint32_t)idx * 0x9E3779B1u + key) ^ ((hi << 16) | (hi >> 16)));
     return (float)(r >> 8) * (1.0f / 16777216.0f);
 }
 

@@ -47,9 +47,13 @@ struct LdsStage {
 // The fragments of k-group g+1 are requested after the first MFMA of group g and before its other three (two
 // register sets; the scheduling fences keep the compiler from moving the reads next to their consumers): a read
 // issued right before the MFMA that needs it idles the matrix pipe for the LDS latency in every group.
-template <bool A_KC, bool B_KC, int K>
-__device__ __forceinline__ void lds_tile_mma(f32x16& acc, const float* A, int lda, int m0, const float* B, int ldb, int n0,
-                                             int lane) {
+//
+// `filler(g)` is independent vector-ALU work of about VALU_PER_GROUP instructions (for example the dropout hash of
+// output element g): it is spread between the MFMAs of k-group g, where the wave would otherwise only wait for the
+// matrix pipe, instead of running as a separate pass after the product.
+template <bool A_KC, bool B_KC, int K, int VALU_PER_GROUP, class Filler>
+__device__ __forceinline__ void lds_tile_mma_fill(f32x16& acc, const float* A, int lda, int m0, const float* B, int ldb,
+                                                  int n0, int lane, Filler filler) {
     static_assert(K % 8 == 0, "k extent is a multiple of the 8-deep fragment group");
     const int li = lane & 31, h = lane >> 5;
     const float* pa = A_KC ? A + (m0 + li) * lda + 4 * h : A + (4 * h) * lda + m0 + li;
@@ -78,10 +82,25 @@ __device__ __forceinline__ void lds_tile_mma(f32x16& acc, const float* A, int ld
         __builtin_amdgcn_sched_barrier(0);
         if (g + 1 < K / 8) read((g + 1) * 8, a[cur ^ 1], b[cur ^ 1]);
         __builtin_amdgcn_sched_barrier(0);
+        filler(g);
 #pragma unroll
         for (int t = 1; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][t], b[cur][t], acc, 0, 0, 0);
+        if (VALU_PER_GROUP > 0) {
+            // one MFMA, then a third of the filler's instructions, three times
+#pragma unroll
+            for (int t = 1; t < 4; ++t) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, (VALU_PER_GROUP + 2) / 3, 0);
+            }
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
+}
+
+template <bool A_KC, bool B_KC, int K>
+__device__ __forceinline__ void lds_tile_mma(f32x16& acc, const float* A, int lda, int m0, const float* B, int ldb, int n0,
+                                             int lane) {
+    lds_tile_mma_fill<A_KC, B_KC, K, 0>(acc, A, lda, m0, B, ldb, n0, lane, [](int) {});
 }
 
 __device__ __forceinline__ void lds_zero(f32x16& a) {

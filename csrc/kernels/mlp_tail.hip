@@ -44,7 +44,13 @@ struct TailArgs {
     float scale1;            // 1 / keep-probability of the first layer's dropout
     float grad_scale;        // 1 / global batch
     float* stats;            // [>=3]: loss sum, correct count, example count
+    long long* prof;         // [32] shader-clock stamps of workgroup 0's second slab (steady state), or null (profiling aid)
 };
+
+#define TAIL_PROF(i)                                                                                    \
+    do {                                                                                                \
+        if (p.prof && tid0 == 0 && slab == (nslabs > (int)gridDim.x ? (int)gridDim.x : 0)) p.prof[i] = (long long)__builtin_readcyclecounter();      \
+    } while (0)
 
 __global__ __launch_bounds__(NT, 1) void mlp_tail_kernel(const TailArgs p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -79,6 +85,8 @@ __global__ __launch_bounds__(NT, 1) void mlp_tail_kernel(const TailArgs p) {
         for (int e = tid; e < 2 * BM * LC + 32; e += NT) sPa[e] = 0.f;
         w2.commit(sW2, tid);
     }
+    if (p.prof && blockIdx.x == 0 && (tid0 & 63) == 0)      // which SIMD each wave of workgroup 0 landed on (HW_ID[5:4])
+        p.prof[16 + (tid0 >> 6)] = (long long)((__builtin_amdgcn_s_getreg(0xF804) >> 4) & 3);
     LdsStage<NT, BM, H> ph;
     int slab = blockIdx.x;
     if (slab < nslabs) {
@@ -100,28 +108,43 @@ __global__ __launch_bounds__(NT, 1) void mlp_tail_kernel(const TailArgs p) {
         const int row0 = slab * BM;
         const int rows = min(BM, p.M - row0);
 
+        TAIL_PROF(0);
         ph.commit(sH1, tid);
         __syncthreads();
+        TAIL_PROF(1);
         if (slab + (int)gridDim.x < nslabs) {
             const int nslab = slab + gridDim.x;
             const int nrows = min(BM, p.M - nslab * BM);
             ph.template issue<false>(p.H1 + (long long)nslab * BM * H, (unsigned)nrows * H * 4, H, tid);
         }
-        // ---- h2 = dropout(relu(h1 W2 + b2)): one 32x32 tile per wave
+        // ---- h2 = dropout(relu(h1 W2 + b2)): one 32x32 tile per wave.  The dropout decision of output element g
+        //      (a counter hash of its index) is computed between the MFMAs of k-group g: H / 8 = 16 groups, 16 elements.
         {
+            static_assert(H / 8 == 16, "one k-group per accumulator register");
             f32x16 acc; lds_zero(acc);
-            lds_tile_mma<true, false, H>(acc, sH1, LH, tm * 32, sW2, LH, tn * 32, lane);
+            float mult[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mult[r] = 1.0f;
+            if (drop2) {
+                const unsigned long long e0 = (unsigned long long)(row0 + tm * 32) * (unsigned)H + col;
+                lds_tile_mma_fill<true, false, H, 30>(acc, sH1, LH, tm * 32, sW2, LH, tn * 32, lane, [&](int g) {
+                    const float u = dtf_uniform(key2, e0 + (unsigned long long)lds_tile_row(g, h) * (unsigned)H);
+                    mult[g] = (u < p.keep2) ? scale2 : 0.f;
+                });
+            } else {
+                lds_tile_mma<true, false, H>(acc, sH1, LH, tm * 32, sW2, LH, tn * 32, lane);
+            }
+            TAIL_PROF(9);
             const float bv = sB2[col];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = tm * 32 + lds_tile_row(r, h);
-                float v = fmaxf(acc[r] + bv, 0.f);
-                if (drop2)
-                    v = (dtf_uniform(key2, (unsigned long long)(row0 + row) * (unsigned)H + col) < p.keep2) ? v * scale2 : 0.f;
-                sH2[row * LH + col] = v;
+                sH2[row * LH + col] = fmaxf(acc[r] + bv, 0.f) * mult[r];
             }
+            TAIL_PROF(10);
         }
         __syncthreads();
+        TAIL_PROF(2);
         // ---- logits: two row tiles x two k-halves on waves 0..3; the halves meet in the softmax pass (fixed order)
         if (wave < 4) {
             const int rt = wave & 1, kh = wave >> 1;
@@ -134,43 +157,52 @@ __global__ __launch_bounds__(NT, 1) void mlp_tail_kernel(const TailArgs p) {
             }
         }
         __syncthreads();
-        // ---- softmax cross-entropy, one thread per row; dz3 replaces the logits (zero in rows past the batch and
-        //      in the padded classes)
-        if (tid < BM) {
-            float* z = sPa + tid * LC;
-            if (tid < rows) {
-                const float* zb = sPb + tid * LC;
-                float v[CP];
-                float mx = -INFINITY;
-                int arg = 0;
+        TAIL_PROF(3);
+        // ---- softmax cross-entropy: eight threads per row, two classes each (the row's maximum, sum and label term
+        //      meet through lane exchanges); dz3 replaces the logits (zero in rows past the batch and in the padded
+        //      classes)
+        {
+            static_assert(CP == 16 && NT == 8 * BM, "eight threads x two classes cover one row of padded logits");
+            const int row = tid >> 3, c0 = 2 * (tid & 7);
+            float* z = sPa + row * LC;
+            if (row < rows) {
+                const float* zb = sPb + row * LC;
+                const bool k0 = c0 < C, k1 = c0 + 1 < C;
+                const float v0 = k0 ? z[c0] + zb[c0] + sB3[c0] : -INFINITY;
+                const float v1 = k1 ? z[c0 + 1] + zb[c0 + 1] + sB3[c0 + 1] : -INFINITY;
+                float mx = v0;
+                int arg = c0;
+                if (v1 > v0) { mx = v1; arg = c0 + 1; }
 #pragma unroll
-                for (int c = 0; c < CP; ++c) {
-                    v[c] = z[c] + zb[c] + sB3[c];
-                    if (c < C && v[c] > mx) { mx = v[c]; arg = c; }
+                for (int d = 1; d < 8; d <<= 1) {            // first maximum wins, as in a left-to-right scan
+                    const float mo = __shfl_xor(mx, d);
+                    const int ao = __shfl_xor(arg, d);
+                    if (mo > mx || (mo == mx && ao < arg)) { mx = mo; arg = ao; }
                 }
-                float se = 0.f;
+                const float e0 = k0 ? __expf(v0 - mx) : 0.f, e1 = k1 ? __expf(v1 - mx) : 0.f;
+                const int label = (int)p.labels[row0 + row];
+                float se = e0 + e1;
+                float zl = (c0 == label) ? e0 : ((c0 + 1 == label) ? e1 : 0.f);
 #pragma unroll
-                for (int c = 0; c < CP; ++c) {
-                    v[c] = c < C ? __expf(v[c] - mx) : 0.f;
-                    se += v[c];
+                for (int d = 1; d < 8; d <<= 1) {
+                    se += __shfl_xor(se, d);
+                    zl += __shfl_xor(zl, d);
                 }
-                const int label = (int)p.labels[row0 + tid];
                 const float inv = 1.0f / se;
-                float zl = 0.f;
-#pragma unroll
-                for (int c = 0; c < CP; ++c) {
-                    if (c == label) zl = v[c];
-                    z[c] = c < C ? (v[c] * inv - (c == label ? 1.f : 0.f)) * p.grad_scale : 0.f;
+                z[c0] = k0 ? (e0 * inv - (c0 == label ? 1.f : 0.f)) * p.grad_scale : 0.f;
+                z[c0 + 1] = k1 ? (e1 * inv - (c0 + 1 == label ? 1.f : 0.f)) * p.grad_scale : 0.f;
+                if ((tid & 7) == 0) {
+                    loss += -__logf(zl * inv);
+                    correct += (arg == label) ? 1.f : 0.f;
+                    count += 1.f;
                 }
-                loss += -__logf(zl * inv);
-                correct += (arg == label) ? 1.f : 0.f;
-                count += 1.f;
             } else {
-#pragma unroll
-                for (int c = 0; c < CP; ++c) z[c] = 0.f;
+                z[c0] = 0.f;
+                z[c0 + 1] = 0.f;
             }
         }
         __syncthreads();
+        TAIL_PROF(4);
         // ---- dW3 += h2^T dz3 (waves 0..3, input-unit block = wave); dz2 products (all waves), both read h2 / dz3
         if (wave < 4) lds_tile_mma<false, false, BM>(g3, sH2, LH, wave * 32, sPa, LC, 0, lane);
         f32x16 az; lds_zero(az);
@@ -181,6 +213,7 @@ __global__ __launch_bounds__(NT, 1) void mlp_tail_kernel(const TailArgs p) {
             db3r += s;
         }
         __syncthreads();
+        TAIL_PROF(5);
         // ---- dz2 = (dz3 W3^T) * (h2 > 0) / keep2 in place of h2
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -189,6 +222,7 @@ __global__ __launch_bounds__(NT, 1) void mlp_tail_kernel(const TailArgs p) {
             sH2[row * LH + col] = (y > 0.f) ? az[r] * scale2 : 0.f;
         }
         __syncthreads();
+        TAIL_PROF(6);
         // ---- dW2 += h1^T dz2: tiles t = wave, wave + 8 (input block t >> 2, output block t & 3); db2
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -204,6 +238,7 @@ __global__ __launch_bounds__(NT, 1) void mlp_tail_kernel(const TailArgs p) {
             }
             db2r += s0 + s1;
         }
+        TAIL_PROF(7);
         // ---- dz1 = (dz2 W2^T) * (h1 > 0) / keep1 -> HBM
         {
             f32x16 a1; lds_zero(a1);
@@ -218,6 +253,7 @@ __global__ __launch_bounds__(NT, 1) void mlp_tail_kernel(const TailArgs p) {
             }
         }
         __syncthreads();     // the next slab overwrites h1 / h2
+        TAIL_PROF(8);
     }
 
     // ---- this workgroup's partial gradients
@@ -237,13 +273,20 @@ __global__ __launch_bounds__(NT, 1) void mlp_tail_kernel(const TailArgs p) {
             for (int r = 0; r < 16; ++r) base[H * H + H + (wave * 32 + lds_tile_row(r, h)) * C + li] = g3[r];
         }
         if (tid0 < C) base[H * H + H + H * C + tid0] = db3r;
-        if (p.stats) {
-            const float l = dtf_wave_sum(loss), a = dtf_wave_sum(correct), n = dtf_wave_sum(count);
-            if (wave == 0 && lane == 0) {          // rows live on threads 0..63 = wave 0 only
-                atomicAdd(p.stats + 0, l);
-                atomicAdd(p.stats + 1, a);
-                atomicAdd(p.stats + 2, n);
-            }
+        // loss / correct / example counts ride in the slab too: thousands of atomic adds on three addresses from
+        // every wave of the grid would serialise in L2 for longer than the kernel runs
+        const float l = dtf_wave_sum(loss), a = dtf_wave_sum(correct), n = dtf_wave_sum(count);
+        if (lane == 0) {
+            sRed[wave * 3 + 0] = l;
+            sRed[wave * 3 + 1] = a;
+            sRed[wave * 3 + 2] = n;
+        }
+        __syncthreads();
+        if (tid0 < 3) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < NT / 64; ++w) t += sRed[w * 3 + tid0];
+            base[H * H + H + H * C + C + tid0] = t;
         }
     }
 }
@@ -252,10 +295,11 @@ __global__ __launch_bounds__(NT, 1) void mlp_tail_kernel(const TailArgs p) {
 // float4 columns with 16 slab-groups (one wave each); the 16 partial sums meet in LDS.
 __global__ __launch_bounds__(1024) void tail_reduce_kernel(const float* __restrict__ slabs, long long slab_stride, int nslabs,
                                                            float* __restrict__ dW2, float* __restrict__ db2,
-                                                           float* __restrict__ dW3, float* __restrict__ db3, int C) {
+                                                           float* __restrict__ dW3, float* __restrict__ db3,
+                                                           float* __restrict__ stats, int C) {
     __shared__ f32x4 part[16][64];
     const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int n_total = H * H + H + H * C + C;
+    const int n_total = H * H + H + H * C + C + 3;       // ... + loss sum, correct count, example count
     const int i = (blockIdx.x * 64 + c) * 4;
     f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
     if (i < n_total) {                        // slab_stride is a multiple of 4 and >= n_total rounded up: in bounds
@@ -281,13 +325,15 @@ __global__ __launch_bounds__(1024) void tail_reduce_kernel(const float* __restri
             if (e < H) { db2[e] = t[j]; continue; }
             e -= H;
             if (e < H * C) { dW3[e] = t[j]; continue; }
-            db3[e - H * C] = t[j];
+            e -= H * C;
+            if (e < C) { db3[e] = t[j]; continue; }
+            if (stats) stats[e - C] += t[j];              // running totals of the epoch; this thread alone owns them here
         }
     }
 }
 
 inline long long slab_stride_for(int C) {
-    const long long n = (long long)H * H + H + (long long)H * C + C;
+    const long long n = (long long)H * H + H + (long long)H * C + C + 3;
     return (n + 3) / 4 * 4;
 }
 inline int grid_for(int M) {
@@ -296,6 +342,14 @@ inline int grid_for(int M) {
 }
 
 }  // namespace
+
+long long* g_tail_prof = nullptr;
+
+// Profiling aid: nine shader-clock stamps of workgroup 0's first slab go to `device_buffer` (null turns it off).
+DTF_API int dtf_mlp_tail_set_profile_buffer(long long* device_buffer) {
+    g_tail_prof = device_buffer;
+    return 0;
+}
 
 DTF_API int dtf_mlp_tail_supported(int H1, int H2, int C) { return (H1 == H && H2 == H && C >= 1 && C <= CP) ? 1 : 0; }
 
@@ -315,7 +369,7 @@ DTF_API int dtf_mlp_tail(const float* H1, const float* W2, const float* b2, cons
     TailArgs a = {};
     a.H1 = H1; a.W2 = W2; a.b2 = b2; a.W3 = W3; a.b3 = b3; a.labels = labels; a.dZ1 = dZ1;
     a.slabs = workspace; a.slab_stride = stride; a.M = M; a.C = C; a.keep2 = keep2; a.seed2 = seed2;
-    a.step_ptr = step_ptr; a.scale1 = scale1; a.grad_scale = grad_scale; a.stats = stats;
+    a.step_ptr = step_ptr; a.scale1 = scale1; a.grad_scale = grad_scale; a.stats = stats; a.prof = g_tail_prof;
     constexpr size_t lds = sizeof(float) * LDS_FLOATS;
     static bool once = false;
     if (!once) {
@@ -326,9 +380,9 @@ DTF_API int dtf_mlp_tail(const float* H1, const float* W2, const float* b2, cons
     }
     hipLaunchKernelGGL(mlp_tail_kernel, dim3(grid), dim3(NT), lds, stream, a);
     DTF_CHECK_LAUNCH();
-    const int n_total = H * H + H + H * C + C;
+    const int n_total = H * H + H + H * C + C + 3;
     hipLaunchKernelGGL(tail_reduce_kernel, dim3((n_total + 255) / 256), dim3(1024), 0, stream, workspace, stride, grid, dW2,
-                       db2, dW3, db3, C);
+                       db2, dW3, db3, stats, C);
     DTF_CHECK_LAUNCH();
     return 0;
 }

@@ -51,8 +51,8 @@ def dropout_key(seed: int, step: int) -> int:
 def dropout_uniform(key: int, n: int, device="cpu") -> torch.Tensor:
     """u[i] in [0,1) for flat element index i: bit-identical to ``dtf_uniform`` on the GPU."""
     idx = torch.arange(n, dtype=torch.int64, device=device)
-    r = _mix32(((idx & _M32) * 0x9E3779B1 + key) & _M32)
-    r = _mix32(r ^ (((idx >> 32) + 0x632BE5AB) & _M32) ^ (key >> 7))
+    hi = (idx >> 32) & _M32
+    r = _mix32((((idx & _M32) * 0x9E3779B1 + key) & _M32) ^ (((hi << 16) | (hi >> 16)) & _M32))
     return (r >> 8).to(torch.float32) * (1.0 / 16777216.0)
 
 
