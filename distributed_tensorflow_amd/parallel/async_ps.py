@@ -121,6 +121,8 @@ class _P2P:
                 self.mail.setdefault((tag, 0), []).append(t.clone())
                 self.cv.notify_all()
             return
+        if _staged(t):
+            t = t.cpu()
         with _NCCL_LOCK:
             w = dist.isend(t, dst=dst, tag=tag, group=self._group(tag))
         w.wait()
@@ -132,9 +134,12 @@ class _P2P:
                     self.cv.wait()
                 t.copy_(self.mail[(tag, 0)].pop(0))
             return
+        h = torch.empty(t.shape, dtype=t.dtype) if _staged(t) else t
         with _NCCL_LOCK:
-            w = dist.irecv(t, src=src, tag=tag, group=self._group(tag))
+            w = dist.irecv(h, src=src, tag=tag, group=self._group(tag))
         w.wait()
+        if h is not t:
+            t.copy_(h)
 
 
     def exchange(self, sends, recvs):
@@ -152,12 +157,17 @@ class _P2P:
                     self.mail.setdefault((tag, 0), []).append(t.clone())
                     self.cv.notify_all()
             else:
-                send_ops.append(dist.P2POp(dist.isend, t, dst, group=self._group(tag), tag=tag))
+                send_ops.append(dist.P2POp(dist.isend, t.cpu() if _staged(t) else t, dst, group=self._group(tag), tag=tag))
+        staged = []
         for t, src, tag in recvs:
             if src == self.rank:
                 local_recvs.append((t, tag))
             else:
-                recv_ops.append(dist.P2POp(dist.irecv, t, src, group=self._group(tag), tag=tag))
+                h = t
+                if _staged(t):
+                    h = torch.empty(t.shape, dtype=t.dtype)
+                    staged.append((t, h))
+                recv_ops.append(dist.P2POp(dist.irecv, h, src, group=self._group(tag), tag=tag))
         works = []
         with _NCCL_LOCK:           # one batch per communicator (a batch may not mix groups)
             if send_ops:
@@ -171,6 +181,14 @@ class _P2P:
                 t.copy_(self.mail[(tag, 0)].pop(0))
         for w in works:
             w.wait()
+        for t, h in staged:
+            t.copy_(h)
+
+
+def _staged(t: torch.Tensor) -> bool:
+    """GPU tensor on the gloo backend (ranks time-sharing one GPU): moved through host memory explicitly, see
+    ``Communicator._staged``."""
+    return t.is_cuda and dist.get_backend() == "gloo"
 
 
 _TAG_PUSH, _TAG_PULL, _TAG_INIT = 11, 12, 13

@@ -74,6 +74,12 @@ class Communicator:
         self.world_size = dist.get_world_size(self.group)
         self.backend = dist.get_backend(self.group)
 
+    def _staged(self, t: torch.Tensor) -> bool:
+        """GPU tensors over gloo (ranks time-sharing one GPU) are staged through host memory here, synchronously:
+        gloo's own device path runs copies on side streams from its worker thread, which has been seen to stall
+        when several freshly started processes share one GPU."""
+        return self.backend == "gloo" and t.is_cuda
+
     # every method returns a Work handle when async_op=True
     def reduce_scatter_sum(self, out_shard: torch.Tensor, full: torch.Tensor, async_op: bool = False):
         """``out_shard = sum over ranks of full[rank*n:(rank+1)*n]``; ``out_shard`` may alias that slice."""
@@ -85,7 +91,7 @@ class Communicator:
             return dist.reduce_scatter_tensor(out_shard, full, op=dist.ReduceOp.SUM, group=self.group,
                                               async_op=async_op)
         # gloo: all-reduce then keep the local slice
-        work = dist.all_reduce(full, op=dist.ReduceOp.SUM, group=self.group, async_op=False)
+        work = self.all_reduce_sum(full)
         n = out_shard.numel()
         src = full[self.rank * n:(self.rank + 1) * n]
         if out_shard.data_ptr() != src.data_ptr():
@@ -101,8 +107,9 @@ class Communicator:
         if self.backend == "nccl":
             return dist.all_gather_into_tensor(full, shard, group=self.group, async_op=async_op)
         n = shard.numel()
-        chunks: List[torch.Tensor] = [torch.empty_like(shard) for _ in range(self.world_size)]
-        dist.all_gather(chunks, shard.clone(), group=self.group)
+        mine = shard.cpu() if self._staged(shard) else shard.clone()
+        chunks: List[torch.Tensor] = [torch.empty_like(mine) for _ in range(self.world_size)]
+        dist.all_gather(chunks, mine, group=self.group)
         for r, c in enumerate(chunks):
             full[r * n:(r + 1) * n].copy_(c)
         return None
@@ -110,17 +117,33 @@ class Communicator:
     def all_reduce_sum(self, t: torch.Tensor, async_op: bool = False):
         if self.world_size == 1:
             return None
+        if self._staged(t):
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            t.copy_(h)
+            return None
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
 
     def broadcast(self, t: torch.Tensor, src: int = 0, async_op: bool = False):
         if self.world_size == 1:
             return None
+        if self._staged(t):
+            h = t.cpu()
+            dist.broadcast(h, src=src, group=self.group)
+            if self.rank != src:
+                t.copy_(h)
+            return None
         return dist.broadcast(t, src=src, group=self.group, async_op=async_op)
 
     def send(self, t: torch.Tensor, dst: int, tag: int = 0):
-        return dist.send(t, dst=dst, group=self.group, tag=tag)
+        return dist.send(t.cpu() if self._staged(t) else t, dst=dst, group=self.group, tag=tag)
 
     def recv(self, t: torch.Tensor, src: int, tag: int = 0):
+        if self._staged(t):
+            h = torch.empty(t.shape, dtype=t.dtype)
+            r = dist.recv(h, src=src, group=self.group, tag=tag)
+            t.copy_(h)
+            return r
         return dist.recv(t, src=src, group=self.group, tag=tag)
 
     def barrier(self):

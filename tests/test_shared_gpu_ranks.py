@@ -3,6 +3,7 @@
 launch and the torchrun launch of bench.py - with the HIP kernels in the loop."""
 import json
 import os
+import signal
 import subprocess
 import sys
 
@@ -22,6 +23,7 @@ def _env(extra=None):
     for k in ("JOB_NAME", "TASK_INDEX", "PS_HOSTS", "WORKER_HOSTS", "RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     env["DTF_COMM_BACKEND"] = "gloo"
+    env["PYTHONFAULTHANDLER"] = "1"          # a process ended with SIGABRT prints the Python stack of every thread
     env["OMP_NUM_THREADS"] = "2"
     env.update(extra or {})
     return env
@@ -45,9 +47,21 @@ def test_one_ps_two_workers_on_one_gpu(tmp_path, mode):
                 rc = procs[key].wait(timeout=WAIT)
             except subprocess.TimeoutExpired:
                 rc = None
+            if rc != 0:
+                # stuck or failed: end exactly the processes this test started, with their stacks in the logs
+                report = []
+                for k2, p2 in procs.items():
+                    if p2.poll() is None:
+                        p2.send_signal(signal.SIGABRT)
+                        try:
+                            p2.wait(timeout=20)
+                        except subprocess.TimeoutExpired:
+                            p2.kill()
+                    logs[k2].seek(0)
+                    report.append("==== %s%d rc=%s\n%s" % (k2[0], k2[1], p2.poll(), logs[k2].read()[-4000:]))
+                raise AssertionError("%s%d rc=%s\n%s" % (key[0], key[1], rc, "\n".join(report)))
             logs[key].seek(0)
             text = logs[key].read()
-            assert rc == 0, "%s%d rc=%s\n%s" % (key[0], key[1], rc, text[-3000:])
             if key[0] == "worker":
                 assert "Training complete!" in text
     finally:
