@@ -109,6 +109,8 @@ __global__ __launch_bounds__(NT, 1) void mlp_tail_kernel(const TailArgs p) {
         const int rows = min(BM, p.M - row0);
 
         TAIL_PROF(0);
+        // this thread's softmax row label, requested now so that the HBM round trip passes under the layer-2 products
+        const int label = ((tid >> 3) < rows) ? (int)p.labels[row0 + (tid >> 3)] : 0;
         ph.commit(sH1, tid);
         __syncthreads();
         TAIL_PROF(1);
@@ -180,7 +182,6 @@ __global__ __launch_bounds__(NT, 1) void mlp_tail_kernel(const TailArgs p) {
                     if (mo > mx || (mo == mx && ao < arg)) { mx = mo; arg = ao; }
                 }
                 const float e0 = k0 ? __expf(v0 - mx) : 0.f, e1 = k1 ? __expf(v1 - mx) : 0.f;
-                const int label = (int)p.labels[row0 + row];
                 float se = e0 + e1;
                 float zl = (c0 == label) ? e0 : ((c0 + 1 == label) ? e1 : 0.f);
 #pragma unroll
@@ -207,10 +208,10 @@ __global__ __launch_bounds__(NT, 1) void mlp_tail_kernel(const TailArgs p) {
         if (wave < 4) lds_tile_mma<false, false, BM>(g3, sH2, LH, wave * 32, sPa, LC, 0, lane);
         f32x16 az; lds_zero(az);
         lds_tile_mma<true, true, CP>(az, sPa, LC, tm * 32, sW3, LC, tn * 32, lane);
-        if (tid < CP) {
-            float s = 0.f;
-            for (int r = 0; r < BM; ++r) s += sPa[r * LC + tid];
-            db3r += s;
+        {   // db3: thread = (class tid & 15, row pair tid >> 4); the partial sums meet after the last slab
+            static_assert(NT == CP * (BM / 2), "one row pair per thread");
+            const float* z = sPa + (2 * (tid >> 4)) * LC + (tid & 15);
+            db3r += z[0] + z[LC];
         }
         __syncthreads();
         TAIL_PROF(5);
@@ -229,12 +230,14 @@ __global__ __launch_bounds__(NT, 1) void mlp_tail_kernel(const TailArgs p) {
             const int t = wave + 8 * q;
             lds_tile_mma<false, false, BM>(g2[q], sH1, LH, (t >> 2) * 32, sH2, LH, (t & 3) * 32, lane);
         }
-        if (tid < H) {
+        {   // db2: thread = (unit tid & 127, row quarter tid >> 7)
+            static_assert(NT == 4 * H && BM % 4 == 0, "four row quarters per hidden unit");
+            const float* z = sH2 + ((tid >> 7) * (BM / 4)) * LH + (tid & (H - 1));
             float s0 = 0.f, s1 = 0.f;
-#pragma unroll 8
-            for (int r = 0; r < BM; r += 2) {
-                s0 += sH2[r * LH + tid];
-                s1 += sH2[(r + 1) * LH + tid];
+#pragma unroll
+            for (int r = 0; r < BM / 4; r += 2) {
+                s0 += z[r * LH];
+                s1 += z[(r + 1) * LH];
             }
             db2r += s0 + s1;
         }
@@ -267,12 +270,12 @@ __global__ __launch_bounds__(NT, 1) void mlp_tail_kernel(const TailArgs p) {
             for (int r = 0; r < 16; ++r)
                 base[((t >> 2) * 32 + lds_tile_row(r, h)) * H + (t & 3) * 32 + li] = g2[q][r];
         }
-        if (tid0 < H) base[H * H + tid0] = db2r;
+        sH1[tid0] = db2r;            // the slab buffers are free now: partial bias sums meet here
+        sH1[NT + tid0] = db3r;
         if (wave < 4 && li < C) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) base[H * H + H + (wave * 32 + lds_tile_row(r, h)) * C + li] = g3[r];
         }
-        if (tid0 < C) base[H * H + H + H * C + tid0] = db3r;
         // loss / correct / example counts ride in the slab too: thousands of atomic adds on three addresses from
         // every wave of the grid would serialise in L2 for longer than the kernel runs
         const float l = dtf_wave_sum(loss), a = dtf_wave_sum(correct), n = dtf_wave_sum(count);
@@ -287,6 +290,14 @@ __global__ __launch_bounds__(NT, 1) void mlp_tail_kernel(const TailArgs p) {
 #pragma unroll
             for (int w = 0; w < NT / 64; ++w) t += sRed[w * 3 + tid0];
             base[H * H + H + H * C + C + tid0] = t;
+        }
+        if (tid0 < H) base[H * H + tid0] = (sH1[tid0] + sH1[H + tid0]) + (sH1[2 * H + tid0] + sH1[3 * H + tid0]);
+        if (tid0 >= NT - CP && tid0 - (NT - CP) < C) {       // a different wave than the db2 sums
+            const int c = tid0 - (NT - CP);
+            float t = 0.f;
+#pragma unroll 8
+            for (int k = 0; k < BM / 2; ++k) t += sH1[NT + k * CP + c];
+            base[H * H + H + H * C + c] = t;
         }
     }
 }
