@@ -49,6 +49,8 @@ def parse_args():
     ap.add_argument("--max-staleness", type=int, default=4, help="async mode: bound on worker clock skew (-1 = unbounded)")
     ap.add_argument("--single-rank-collectives", type=int, default=0,
                     help="testing aid: run the multi-GPU code path (RCCL calls included) on a 1-rank process group")
+    ap.add_argument("--allreduce", default="rccl", choices=["rccl", "p2p"],
+                    help="small-model gradient exchange: RCCL all-reduce, or the one-shot peer-pointer kernel (one node)")
     ap.add_argument("--eval", type=int, default=0, help="also train for this many extra steps and report test accuracy")
     return ap.parse_args()
 
@@ -58,6 +60,8 @@ DEFAULT_BATCH = {"mnist_mlp": 131072, "xor_mlp": 32768, "mnist_cnn": 1024, "wide
 
 def main():
     args = parse_args()
+    if args.allreduce == "p2p":
+        os.environ["DTF_ALLREDUCE"] = "p2p"
     import torch
     import torch.distributed as dist
 
@@ -222,7 +226,7 @@ def main():
             "data": "synthetic (device-resident MNIST-shaped inputs, random-init weights)",
             "config": {"model": args.model, "global_batch": global_batch, "batch_per_gpu": B, "seq_len": None,
                        "parallelism": ("dp%d" if args.mode == "sync" else "async-ps%d") % world, "params": model.store.num_params,
-                       "optimizer": "adam", "hip_graph": bool(use_graph), "fused_step_kernel": plan is not None,
+                       "optimizer": "adam", "hip_graph": bool(use_graph), "fused_step_kernel": plan is not None, "allreduce": args.allreduce if multi else None,
                        "train_loss": logs.get("loss"), "train_acc": logs.get("acc"), "test_acc": test_acc,
                        **({"max_staleness": args.max_staleness, "staleness_histogram_rank0": staleness}
                           if staleness is not None else {})},

@@ -92,6 +92,12 @@ class SyncReplicasStrategy:
             self.buckets = []
             self._layer_bucket = {}
             model._after_layer_backward = None
+            # DTF_ALLREDUCE=p2p: the ranks of one node add up each other's gradient buffers through mapped peer
+            # memory in one hop (parallel/p2p_allreduce.py) instead of a ring all-reduce
+            self.p2p = None
+            if os.environ.get("DTF_ALLREDUCE", "") == "p2p" and self.comm.world_size > 1 and store.device.type == "cuda":
+                from .p2p_allreduce import P2PAllReduce
+                self.p2p = P2PAllReduce(store.flat_len, store.device, group=self.comm.group)
             return
         self._build_buckets(model)
         model._after_layer_backward = self._on_layer_backward if self.overlap else None
@@ -157,6 +163,9 @@ class SyncReplicasStrategy:
             if c.world_size == 1:      # forced single-rank collective (GPU-box test of the RCCL call path)
                 import torch.distributed as dist
                 work = dist.all_reduce(store.flat_grad, group=c.group, async_op=True) if c.backend == "nccl" else None
+            elif getattr(self, "p2p", None) is not None:
+                self.p2p.all_reduce_sum(store.flat_grad)
+                work = None
             else:
                 work = c.all_reduce_sum(store.flat_grad, async_op=(c.backend == "nccl"))
             if work is not None and hasattr(work, "wait"):

@@ -74,15 +74,18 @@ def test_one_ps_two_workers_on_one_gpu(tmp_path, mode):
     assert ck is not None and 200 <= int(ck.rsplit("-", 1)[1]) <= 204
 
 
-def test_bench_two_ranks_share_the_gpu():
-    """bench.py launched exactly as the multi-GPU driver launches it (torch.distributed.run, 2 ranks)."""
+@pytest.mark.parametrize("allreduce", ["rccl", "p2p"])
+def test_bench_two_ranks_share_the_gpu(allreduce):
+    """bench.py launched exactly as the multi-GPU driver launches it (torch.distributed.run, 2 ranks); "rccl" is the
+    default gradient all-reduce (gloo stands in here), "p2p" the one-shot peer-pointer kernel."""
     port = _ports(1)[0]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
-           "--batch-per-gpu", "4096"]
+           "--batch-per-gpu", "4096", "--allreduce", allreduce]
     out = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=WAIT, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8192 and d["config"]["parallelism"] == "dp2"
-    assert d["value"] > 0 and d["steps"] == 6
+    assert d["value"] > 0 and d["steps"] == 6 and d["config"]["allreduce"] == allreduce
+    assert d["config"]["train_loss"] == d["config"]["train_loss"]      # finite, not NaN
