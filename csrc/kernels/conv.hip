@@ -135,6 +135,65 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
     }
 }
 
+// Four channels per thread (C % 4 == 0): 16-byte accesses and a quarter of the index arithmetic.
+__global__ __launch_bounds__(256) void maxpool_fwd4_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                           unsigned char* __restrict__ arg, const PoolGeom g, long long total) {
+    const int CV = g.C / 4;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int c = (int)(idx % CV) * 4;
+        const long long pix = idx / CV;
+        const int ow = (int)(pix % g.OW);
+        const int oh = (int)((pix / g.OW) % g.OH);
+        const int b = (int)(pix / ((long long)g.OW * g.OH));
+        f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int bi[4] = {0, 0, 0, 0};
+        for (int i = 0; i < g.PH; ++i)
+            for (int j = 0; j < g.PW; ++j) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(
+                    x + (((long long)b * g.H + oh * g.PH + i) * g.W + ow * g.PW + j) * g.C + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (v[e] > best[e]) { best[e] = v[e]; bi[e] = i * g.PW + j; }
+            }
+        *reinterpret_cast<f32x4*>(y + pix * g.C + c) = best;
+        *reinterpret_cast<uchar4*>(arg + pix * g.C + c) =
+            make_uchar4((unsigned char)bi[0], (unsigned char)bi[1], (unsigned char)bi[2], (unsigned char)bi[3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd4_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ arg,
+                                                           const float* __restrict__ x_relu, float* __restrict__ dx,
+                                                           const PoolGeom g, long long total) {
+    const int CV = g.C / 4;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int c = (int)(idx % CV) * 4;
+        const long long pix = idx / CV;
+        const int iw = (int)(pix % g.W);
+        const int ih = (int)((pix / g.W) % g.H);
+        const int b = (int)(pix / ((long long)g.W * g.H));
+        const int oh = ih / g.PH, ow = iw / g.PW;
+        f32x4 r = {0.f, 0.f, 0.f, 0.f};
+        if (oh < g.OH && ow < g.OW) {
+            const long long o = (((long long)b * g.OH + oh) * g.OW + ow) * g.C + c;
+            const int me = (ih - oh * g.PH) * g.PW + (iw - ow * g.PW);
+            const uchar4 a = *reinterpret_cast<const uchar4*>(arg + o);
+            const f32x4 d = *reinterpret_cast<const f32x4*>(dy + o);
+            r[0] = (int)a.x == me ? d[0] : 0.f;
+            r[1] = (int)a.y == me ? d[1] : 0.f;
+            r[2] = (int)a.z == me ? d[2] : 0.f;
+            r[3] = (int)a.w == me ? d[3] : 0.f;
+        }
+        const long long dst = pix * g.C + c;
+        if (x_relu) {
+            const f32x4 xr = *reinterpret_cast<const f32x4*>(x_relu + dst);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (!(xr[e] > 0.f)) r[e] = 0.f;
+        }
+        *reinterpret_cast<f32x4*>(dx + dst) = r;
+    }
+}
+
 inline int grid_for(long long total) {
     long long blocks = (total + 255) / 256;
     const long long cap = 256 * 32;      // grid-stride beyond 32 blocks per CU
@@ -185,7 +244,10 @@ DTF_API int dtf_maxpool_fwd(const float* x, float* y, unsigned char* arg, int B,
     if (B <= 0 || H < PH || W < PW || C <= 0 || PH <= 0 || PW <= 0 || PH * PW > 255) return -3;
     const PoolGeom g = {B, H, W, C, PH, PW, H / PH, W / PW};
     const long long total = (long long)B * g.OH * g.OW * C;
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, y, arg, g, total);
+    if (C % 4 == 0)
+        hipLaunchKernelGGL(maxpool_fwd4_kernel, dim3(grid_for(total / 4)), dim3(256), 0, stream, x, y, arg, g, total / 4);
+    else
+        hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, y, arg, g, total);
     DTF_CHECK_LAUNCH();
     return 0;
 }
@@ -195,7 +257,11 @@ DTF_API int dtf_maxpool_bwd(const float* dy, const unsigned char* arg, const flo
     if (B <= 0 || H < PH || W < PW || C <= 0 || PH <= 0 || PW <= 0 || PH * PW > 255) return -3;
     const PoolGeom g = {B, H, W, C, PH, PW, H / PH, W / PW};
     const long long total = (long long)B * H * W * C;
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, dy, arg, x_relu, dx, g, total);
+    if (C % 4 == 0)
+        hipLaunchKernelGGL(maxpool_bwd4_kernel, dim3(grid_for(total / 4)), dim3(256), 0, stream, dy, arg, x_relu, dx, g,
+                           total / 4);
+    else
+        hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, dy, arg, x_relu, dx, g, total);
     DTF_CHECK_LAUNCH();
     return 0;
 }

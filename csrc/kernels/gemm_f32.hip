@@ -654,6 +654,70 @@ DTF_API int dtf_dense_fwd(const float* X, const float* W, const float* bias, flo
     return launch_gemm<true, false, EPI_FWD>(a, 1, stream);
 }
 
+// Forward products with few output tiles and a long K (a wide layer at a small batch, e.g. 1024 x 3136 -> 512: 128
+// tiles for 256 CUs) split K over blockIdx.z into slabs; this kernel adds the slabs, the bias, the activation and the dropout mask.
+__global__ __launch_bounds__(256) void reduce_fwd_slabs_kernel(const float* __restrict__ slabs, long long slab_stride,
+                                                               int splits, const float* __restrict__ bias, int act,
+                                                               float keep, uint32_t seed, const long long* step_ptr,
+                                                               float* __restrict__ Y, int N, long long total4) {
+    const bool drop = keep < 1.0f;
+    const uint32_t key = drop ? dtf_dropout_key(seed, step_ptr) : 0u;
+    const float inv_keep = drop ? 1.0f / keep : 1.0f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+        f32x4 acc = *reinterpret_cast<const f32x4*>(slabs + 4 * i);
+        for (int s = 1; s < splits; ++s) acc += *reinterpret_cast<const f32x4*>(slabs + (long long)s * slab_stride + 4 * i);
+        const int col = (int)((4 * i) % N);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = acc[e] + (bias ? bias[col + e] : 0.f);
+            if (act == ACT_RELU) v = fmaxf(v, 0.f);
+            else if (act == ACT_SIGMOID) v = dtf_sigmoid(v);
+            if (drop) v = (dtf_uniform(key, (unsigned long long)(4 * i + e)) < keep) ? v * inv_keep : 0.f;   // index = row * N + col
+            acc[e] = v;
+        }
+        *reinterpret_cast<f32x4*>(Y + 4 * i) = acc;
+    }
+}
+
+// K splits of the forward product (1 = no split).  Only products that cannot fill the chip with output tiles split.
+DTF_API int dtf_dense_fwd_splits(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K < 1024 || N % 4 != 0 || N <= 32) return 1;
+    const long long tiles = (long long)((M + 63) / 64) * ((N + 63) / 64);     // the smallest tile gives the most blocks
+    if (tiles >= 256) return 1;
+    long long s = 512 / tiles;
+    const long long by_k = K / 256;                                           // at least 8 k-tiles per split
+    if (s > by_k) s = by_k;
+    return s < 2 ? 1 : (int)s;
+}
+
+// dtf_dense_fwd with scratch for the K-split path: workspace holds splits * M * N floats.
+DTF_API int dtf_dense_fwd_ws(const float* X, const float* W, const float* bias, float* Y, int M, int N, int K, int act,
+                             float keep, uint32_t seed, const long long* step_ptr, float* workspace,
+                             long long workspace_floats, hipStream_t stream) {
+    const int splits = dtf_dense_fwd_splits(M, N, K);
+    const long long slab = (long long)M * N;
+    if (splits <= 1 || !workspace || workspace_floats < splits * slab)
+        return dtf_dense_fwd(X, W, bias, Y, M, N, K, act, keep, seed, step_ptr, stream);
+    GemmArgs a = {};
+    a.A = X; a.lda = K;
+    a.B = W; a.ldb = N;
+    a.C = workspace; a.ldc = N; a.c_split_stride = slab;
+    a.M = M; a.N = N; a.K = K;
+    int chunk = (K + splits - 1) / splits;
+    chunk = ((chunk + BK - 1) / BK) * BK;
+    a.k_chunk = chunk;
+    const int eff = (K + chunk - 1) / chunk;
+    int rc = launch_gemm<true, false, EPI_DW>(a, eff, stream);      // plain stores of the partial products
+    if (rc) return rc;
+    const long long total4 = slab / 4;
+    long long blocks = (total4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(reduce_fwd_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, workspace, slab, eff, bias, act, keep,
+                       seed, step_ptr, Y, N, total4);
+    DTF_CHECK_LAUNCH();
+    return 0;
+}
+
 // dX[M,K] = dZ[M,N] . W[K,N]^T, then (optionally) the producing layer's activation and
 // dropout gradient: relu -> (Yprev > 0) * scale_prev, sigmoid -> Yprev (1 - Yprev).
 DTF_API int dtf_dense_bwd_dx(const float* dZ, const float* W, float* dX, int M, int N, int K,

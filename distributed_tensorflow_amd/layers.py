@@ -148,8 +148,13 @@ class Dense(Layer):
         M = x.shape[0]
         keep = self.fused_keep if training else 1.0
         y = self._buf.get("y", (M, self.units), x.device)
+        ws = None
+        if x.is_cuda:
+            need = F.dense_fwd_workspace_floats(M, self.units, x.shape[1])      # long K, few output tiles: K is split
+            if need:
+                ws = self._buf.get("fwd_ws", (need,), x.device)
         F.dense_forward(x, self.kernel.tensor, self.bias.tensor if self.bias is not None else None, self.act,
-                        keep, self.seed, self.store.global_step, out=y)
+                        keep, self.seed, self.store.global_step, out=y, workspace=ws)
         self._x, self._y, self._keep_used = x, y, keep
         if self.softmax and not self.emit_logits:
             # probabilities are only materialised when no fused cross-entropy consumes the logits

@@ -52,6 +52,8 @@ def kernels():
     lib = _load("libdtf_kernels.so")
     sig = {
         "dtf_dense_fwd": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_u32, c_p, c_p],
+        "dtf_dense_fwd_ws": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_u32, c_p, c_p, c_ll, c_p],
+        "dtf_dense_fwd_splits": [c_i, c_i, c_i],
         "dtf_dense_bwd_dx": [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_f, c_p],
         "dtf_dense_bwd_dw_splits": [c_i, c_i, c_i],
         "dtf_dense_bwd_dw": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p],

@@ -73,7 +73,15 @@ def _apply_act(z: torch.Tensor, act: int) -> torch.Tensor:
     return z
 
 
-def dense_forward(x, w, b=None, act=ACT_NONE, keep=1.0, seed=0, step=None, out=None):
+def dense_fwd_workspace_floats(M: int, N: int, K: int) -> int:
+    """Floats of scratch with which ``dense_forward`` may split a long K (few output tiles); 0 = never splits."""
+    if not nv.kernels_available():
+        return 0
+    s = nv.kernels().dtf_dense_fwd_splits(M, N, K)
+    return s * M * N if s > 1 else 0
+
+
+def dense_forward(x, w, b=None, act=ACT_NONE, keep=1.0, seed=0, step=None, out=None, workspace=None):
     """``dropout(act(x @ w + b))`` with inverted dropout (keep probability ``keep``)."""
     M, K = x.shape
     K2, N = w.shape
@@ -84,8 +92,13 @@ def dense_forward(x, w, b=None, act=ACT_NONE, keep=1.0, seed=0, step=None, out=N
         nv.require_f32_contig(x, w, b, out)
         if step is not None:
             assert step.dtype == torch.int64 and step.is_cuda
-        rc = nv.kernels().dtf_dense_fwd(nv.ptr(x), nv.ptr(w), nv.ptr(b), nv.ptr(out), M, N, K, int(act),
-                                        float(keep), int(seed) & _M32, nv.ptr(step), nv.stream_ptr())
+        if workspace is not None:
+            rc = nv.kernels().dtf_dense_fwd_ws(nv.ptr(x), nv.ptr(w), nv.ptr(b), nv.ptr(out), M, N, K, int(act),
+                                               float(keep), int(seed) & _M32, nv.ptr(step), nv.ptr(workspace),
+                                               workspace.numel(), nv.stream_ptr())
+        else:
+            rc = nv.kernels().dtf_dense_fwd(nv.ptr(x), nv.ptr(w), nv.ptr(b), nv.ptr(out), M, N, K, int(act),
+                                            float(keep), int(seed) & _M32, nv.ptr(step), nv.stream_ptr())
         nv.check(rc, "dtf_dense_fwd")
         return out
     z = x @ w

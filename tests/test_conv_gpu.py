@@ -48,16 +48,17 @@ def test_conv_as_gemm_matches_torch_conv2d(gpu_device, g):
     torch.testing.assert_close(y.cpu().view(ref.shape), ref, rtol=1e-4, atol=1e-4)
 
 
-def test_maxpool(gpu_device):
+@pytest.mark.parametrize("C,pool", [(5, (2, 2)), (8, (2, 2)), (32, (3, 2))])     # scalar and 4-channel vector kernels
+def test_maxpool(gpu_device, C, pool):
     gen = torch.Generator().manual_seed(2)
-    x = torch.randn(3, 9, 10, 5, generator=gen)
-    y_ref, a_ref = F.maxpool_forward(x, (2, 2))
-    y, a = F.maxpool_forward(x.to(gpu_device), (2, 2))
+    x = torch.randn(3, 9, 10, C, generator=gen)
+    y_ref, a_ref = F.maxpool_forward(x, pool)
+    y, a = F.maxpool_forward(x.to(gpu_device), pool)
     assert torch.equal(y.cpu(), y_ref) and torch.equal(a.cpu(), a_ref)
     dy = torch.randn(y_ref.shape, generator=gen)
     for xr in (None, torch.relu(x)):
-        ref = F.maxpool_backward(dy, a_ref, x.shape, (2, 2), x_relu=xr)
-        got = F.maxpool_backward(dy.to(gpu_device), a, x.shape, (2, 2), x_relu=None if xr is None else xr.to(gpu_device))
+        ref = F.maxpool_backward(dy, a_ref, x.shape, pool, x_relu=xr)
+        got = F.maxpool_backward(dy.to(gpu_device), a, x.shape, pool, x_relu=None if xr is None else xr.to(gpu_device))
         assert torch.equal(got.cpu(), ref)
 
 

@@ -185,3 +185,26 @@ def test_xor_generator_matches_cpu(gpu_device):
     assert torch.equal(x.cpu(), xc) and torch.equal(y.cpu(), yc)
     assert torch.equal(y, (x[:, :32] != x[:, 32:]).float())
     assert abs(x.mean().item() - 0.5) < 0.01
+
+
+def test_dense_forward_splits_a_long_k_with_few_output_tiles(gpu_device):
+    """1024 x 3136 -> 512 (the CNN's first dense layer): K is split into slabs, bias and ReLU follow in the reducer."""
+    M, K, N = 1024, 3136, 512
+    need = F.dense_fwd_workspace_floats(M, N, K)
+    assert need >= 2 * M * N
+    g = torch.Generator().manual_seed(4)
+    x = (torch.rand(M, K, generator=g) - 0.5).to(gpu_device)
+    w = ((torch.rand(K, N, generator=g) - 0.5) * 0.1).to(gpu_device)
+    b = torch.rand(N, generator=g).to(gpu_device)
+    ws = torch.empty(need, device=gpu_device)
+    for act in (0, 1, 2):
+        y = F.dense_forward(x, w, b, act, workspace=ws)
+        ref = x.double() @ w.double() + b.double()
+        ref = torch.relu(ref) if act == 1 else (torch.sigmoid(ref) if act == 2 else ref)
+        torch.testing.assert_close(y.double(), ref, rtol=2e-5, atol=2e-5)
+        torch.testing.assert_close(y, F.dense_forward(x, w, b, act), rtol=1e-5, atol=1e-5)     # unsplit path agrees
+    step = torch.tensor([7], dtype=torch.int64, device=gpu_device)
+    yd = F.dense_forward(x, w, b, 1, keep=0.7, seed=31, step=step, workspace=ws)
+    torch.testing.assert_close(yd, F.dense_forward(x, w, b, 1, keep=0.7, seed=31, step=step), rtol=1e-5, atol=1e-5)
+    assert 0.25 < (yd == 0).float().mean() < 0.9                       # ReLU zeros plus 30 % dropped
+    assert F.dense_fwd_workspace_floats(65536, 128, 784) == 0          # plenty of tiles: never split
