@@ -43,6 +43,29 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x
     }
 }
 
+// Single-channel images (the first convolution of an MNIST network): one thread per (output pixel, kernel row) writes
+// the KW consecutive patch entries of that row, so the pixel decode - integer divisions - is paid once per KW elements.
+__global__ __launch_bounds__(256) void im2col_c1_kernel(const float* __restrict__ x, float* __restrict__ cols, const ConvGeom g,
+                                                        long long total) {
+    const int K = g.KH * g.KW;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const long long m = idx / g.KH;
+        const int kh = (int)(idx - m * g.KH);
+        const int ow = (int)(m % g.OW);
+        const int oh = (int)((m / g.OW) % g.OH);
+        const int b = (int)(m / ((long long)g.OW * g.OH));
+        const int ih = oh * g.sh - g.pad_t + kh;
+        const int iw0 = ow * g.sw - g.pad_l;
+        const bool row_in = ih >= 0 && ih < g.H;
+        const float* src = x + ((long long)b * g.H + ih) * g.W;
+        float* dst = cols + m * K + kh * g.KW;
+        for (int kw = 0; kw < g.KW; ++kw) {
+            const int iw = iw0 + kw;
+            dst[kw] = (row_in && iw >= 0 && iw < g.W) ? src[iw] : 0.f;
+        }
+    }
+}
+
 // dx[b][ih][iw][c] = sum over (kh, kw) of dcols[(b, oh, ow)][(kh*KW + kw)*C + c] with oh*sh - pad_t + kh == ih (same for w);
 // optionally times the producing layer's ReLU gradient (yprev > 0).
 template <int V>
@@ -216,6 +239,9 @@ DTF_API int dtf_im2col(const float* x, float* cols, int B, int H, int W, int C, 
     if (C % 4 == 0) {
         const long long total = M * (K / 4);
         hipLaunchKernelGGL(im2col_kernel<4>, dim3(grid_for(total)), dim3(256), 0, stream, x, cols, g, total);
+    } else if (C == 1) {
+        const long long total = M * KH;
+        hipLaunchKernelGGL(im2col_c1_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, cols, g, total);
     } else {
         const long long total = M * K;
         hipLaunchKernelGGL(im2col_kernel<1>, dim3(grid_for(total)), dim3(256), 0, stream, x, cols, g, total);
