@@ -74,7 +74,8 @@ def test_member_that_never_appears_is_lost_after_the_grace_period():
         srv.stop()
 
 
-def test_gang_restart_after_a_worker_is_killed(tmp_path):
+@pytest.mark.parametrize("victim", ["worker:1", "ps:0"])
+def test_gang_restart_after_a_task_is_killed(tmp_path, victim):
     log_dir, run_dir = str(tmp_path / "logs"), str(tmp_path / "run")
     last_step = 6000
     env = _env({"DTF_HEARTBEAT_MAX_AGE_SECS": "2", "DTF_HEARTBEAT_ABORT_SECS": "2", "PYTHONPATH": ROOT})
@@ -84,7 +85,8 @@ def test_gang_restart_after_a_worker_is_killed(tmp_path):
          "--last_step", str(last_step), "--save_checkpoint_secs", "0.3"],
         env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, cwd=ROOT)
     try:
-        # wait until the first gang has written a checkpoint well into the run, then kill exactly worker 1
+        # wait until the first gang has written a checkpoint well into the run, then kill exactly one task: a worker,
+        # or the parameter server (which also hosts the control plane the others heartbeat to)
         def progressed():
             ck = latest_checkpoint(log_dir) if os.path.isdir(log_dir) else None
             return ck is not None and int(ck.rsplit("-", 1)[1]) >= 300
@@ -95,7 +97,7 @@ def test_gang_restart_after_a_worker_is_killed(tmp_path):
         assert info["attempt"] == 0
         killed_at = int(latest_checkpoint(log_dir).rsplit("-", 1)[1])
         assert killed_at < last_step, "run finished before the fault could be injected"
-        os.kill(info["pids"]["worker:1"], signal.SIGKILL)
+        os.kill(info["pids"][victim], signal.SIGKILL)
         out, _ = launcher.communicate(timeout=300)
     finally:
         if launcher.poll() is None:
