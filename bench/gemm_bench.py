@@ -14,6 +14,7 @@ shapes = [(M, 784, 128), (M, 128, 128), (M, 128, 10)]
 if os.environ.get("SHAPE"):                      # SHAPE=m,k,n times that single product
     shapes = [tuple(int(v) for v in os.environ["SHAPE"].split(","))]
 rounds = 20
+BF16 = os.environ.get("BF16", "0") == "1"     # bf16-operand kernels (wide shapes only)
 
 
 def timeit(fn):
@@ -44,14 +45,14 @@ for (m, k, n) in shapes:
 
     def fwd():
         it[0] += 1
-        F.dense_forward(xs[it[0] % 3], w, b, 1, out=y)
+        F.dense_forward(xs[it[0] % 3], w, b, 1, out=y, bf16=BF16)
 
     def bdx():
-        F.dense_backward_dx(dz, w, xs[0], 1, 1.0, out=dx)
+        F.dense_backward_dx(dz, w, xs[0], 1, 1.0, out=dx, bf16=BF16)
 
     def bdw():
         it[0] += 1
-        F.dense_backward_dw(xs[it[0] % 3], dz, dw, db, workspace=ws)
+        F.dense_backward_dw(xs[it[0] % 3], dz, dw, db, workspace=ws, bf16=BF16)
 
     flop = 2.0 * m * k * n
     for name, fn in (("fwd", fwd), ("dx", bdx), ("dw", bdw)):

@@ -32,6 +32,11 @@ namespace {
 
 constexpr int BK = 32;
 constexpr int LDK = BK + 4;  // row stride (floats) of a k-contiguous LDS tile
+constexpr int LDKB = BK + 8; // row stride (bf16 elements, 80 bytes) of a bf16 LDS tile: 16-byte fragment reads of 8
+                             // consecutive rows fall into distinct bank groups
+
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 enum { EPI_FWD = 0, EPI_DX = 1, EPI_DW = 2 };
 
@@ -165,7 +170,86 @@ struct TileLoader {
             *reinterpret_cast<f32x4*>(lds + off) = x;
         }
     }
+
+    // bf16 image for the bf16-operand kernel, ALWAYS k-contiguous: [ROWS][LDKB] of bf16 (round to nearest even).
+    // A k-contiguous source writes its 4 values as one 8-byte store; an M/N-contiguous source is transposed on the
+    // way in (4 two-byte stores to 4 consecutive rows).
+    __device__ __forceinline__ void store_bf16(unsigned short* lds, int k_left, int tid) const {
+#pragma unroll
+        for (int s = 0; s < NV; ++s) {
+            const int id = tid + 256 * s;
+            f32x4 x = v[s];
+            if (KC) {
+                const int r = id >> 3, c = (id & 7) * 4;
+                const int lim = k_left - c;
+#pragma unroll
+                for (int j = 1; j < 4; ++j) x[j] = (j < lim) ? x[j] : 0.f;
+                bf16x4 y;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) y[j] = (__bf16)x[j];
+                *reinterpret_cast<bf16x4*>(lds + r * LDKB + c) = y;
+            } else {
+                const int c = id / (ROWS / 4), r = (id % (ROWS / 4)) * 4;      // c = k index, r = first of 4 rows
+                const int lim = mn_left - r;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const __bf16 y = (__bf16)((j == 0 || j < lim) ? x[j] : 0.f);
+                    lds[(r + j) * LDKB + c] = __builtin_bit_cast(unsigned short, y);
+                }
+            }
+        }
+    }
 };
+
+// Loader of an M/N-contiguous operand for the bf16 kernel.  The LDS image must be k-contiguous, so the tile is
+// transposed on the way in; a thread therefore owns 4 CONSECUTIVE k rows of the same 4 M/N columns (4 float4 loads)
+// and writes each column's 4 k values as one 8-byte store - a quarter of the LDS stores of a per-element scatter.
+template <int ROWS>
+struct TransposeLoader {
+    static constexpr int NV = 4;
+    static_assert(ROWS == 128, "256 threads x (4 k rows x 4 columns) cover a 32 x 128 tile");
+    __amdgpu_buffer_rsrc_t rsrc;
+    int ld, mn_left;
+    unsigned voff[NV];
+    f32x4 v[NV];
+
+    __device__ __forceinline__ void init(const float* base, int ld_, int mn0, int mn_dim, int kbeg, int k_total) {
+        ld = ld_;
+        mn_left = mn_dim - mn0;
+        rsrc = make_rsrc(base + (long long)kbeg * ld + mn0, (((long long)(k_total - kbeg)) * ld - mn0) * 4);
+        const int tid = threadIdx.x;
+        const int r = (tid & 31) * 4, c0 = (tid >> 5) * 4;
+#pragma unroll
+        for (int s = 0; s < NV; ++s)
+            voff[s] = (r < mn_left) ? ((unsigned)(c0 + s) * (unsigned)ld + (unsigned)r) * 4u : OOB;
+    }
+    __device__ __forceinline__ void load(int k0, int kbeg, int k_left, int tid) {
+        const unsigned koff = (unsigned)(k0 - kbeg) * (unsigned)ld * 4u;
+        const int c0 = (tid >> 5) * 4;
+#pragma unroll
+        for (int s = 0; s < NV; ++s) {
+            const bool ok = (voff[s] != OOB) && (c0 + s < k_left);
+            const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(ok ? voff[s] + koff : OOB), 0, 0);
+            v[s] = __builtin_bit_cast(f32x4, raw);
+        }
+    }
+    __device__ __forceinline__ void store_bf16(unsigned short* lds, int k_left, int tid) const {
+        const int r = (tid & 31) * 4, c0 = (tid >> 5) * 4;
+        const int lim = mn_left - r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bf16x4 y;
+#pragma unroll
+            for (int s = 0; s < NV; ++s) y[s] = (__bf16)((j == 0 || j < lim) ? v[s][j] : 0.f);
+            *reinterpret_cast<bf16x4*>(lds + (r + j) * LDKB + c0) = y;
+        }
+    }
+};
+
+template <int ROWS, bool KC>
+struct PickBf16Loader { using type = TileLoader<ROWS, true>; };
+template <int ROWS>
+struct PickBf16Loader<ROWS, false> { using type = TransposeLoader<ROWS>; };
 
 // Operand-A loaders of the implicit-GEMM convolution: same LDS images and the same load()/store() protocol as
 // TileLoader, but the global address of patch element (m, k) is rowtab[m] + shift[k / C] + k % C in the padded image.
@@ -278,6 +362,77 @@ template <bool GATHER, int ROWS, bool KC>
 struct PickLoader { using type = TileLoader<ROWS, KC>; };
 template <int ROWS, bool KC>
 struct PickLoader<true, ROWS, KC> { using type = GatherLoader<ROWS, KC>; };
+
+// Epilogue shared by the fp32 and the bf16-operand kernels (the C/D layout of the 32x32 MFMAs does not depend on the
+// operand type): col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+template <int TM, int TN, int BM, int BN, int EPI>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int li,
+                                              int h) {
+    float* C = p.C + (long long)blockIdx.z * p.c_split_stride;
+    uint32_t key = 0;
+    const bool drop = (EPI == EPI_FWD) && (p.keep < 1.0f);
+    float inv_keep = 1.0f;
+    if (drop) {
+        key = dtf_dropout_key(p.seed, p.step_ptr);
+        inv_keep = 1.0f / p.keep;
+    }
+    // A tile that lies entirely inside C (all of them except the last row / column of tiles) skips the per-element
+    // bounds tests: with them the epilogue is several thousand instructions and costs about a tenth of a short-K GEMM.
+    const float relu_floor = (p.act == ACT_RELU) ? 0.f : -INFINITY;
+    auto write_tile = [&](auto checked, auto simple) {
+        constexpr bool CHECK = decltype(checked)::value;
+        constexpr bool SIMPLE = decltype(simple)::value;   // forward: bias and ReLU / identity only; dgrad: ReLU mask or none
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + (wn * TN + j) * 32 + li;
+                if (CHECK && col >= p.N) continue;
+                float bv = 0.f;
+                if (EPI == EPI_FWD && p.bias) bv = p.bias[col];
+                const int row0 = m0 + (wm * TM + i) * 32 + 4 * h;
+                float* Cp = C + (long long)row0 * p.ldc + col;
+                const float* Yp = (EPI == EPI_DX && p.yprev) ? p.yprev + (long long)row0 * p.ldy + col : nullptr;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dr = (r & 3) + 8 * (r >> 2);
+                    if (CHECK && row0 + dr >= p.M) continue;
+                    float v = acc[i][j][r];
+                    if (EPI == EPI_FWD) {
+                        v += bv;
+                        if (SIMPLE) {
+                            v = fmaxf(v, relu_floor);
+                        } else {
+                            if (p.act == ACT_SIGMOID) v = dtf_sigmoid(v);
+                            else v = fmaxf(v, relu_floor);
+                            if (drop) {
+                                const float u = dtf_uniform(key, (unsigned long long)(row0 + dr) * (unsigned)p.N + col);
+                                v = (u < p.keep) ? v * inv_keep : 0.f;
+                            }
+                        }
+                    } else if (EPI == EPI_DX) {
+                        if (SIMPLE) {
+                            if (Yp) v = (Yp[(long long)dr * p.ldy] > 0.f) ? v * p.scale_prev : 0.f;
+                        } else if (Yp) {
+                            const float y = Yp[(long long)dr * p.ldy];
+                            if (p.act == ACT_RELU) v = (y > 0.f) ? v * p.scale_prev : 0.f;
+                            else if (p.act == ACT_SIGMOID) v = v * y * (1.0f - y);
+                        }
+                    }
+                    Cp[(long long)dr * p.ldc] = v;
+                }
+            }
+        }
+    };
+    const bool simple = (EPI == EPI_FWD) ? (!drop && p.act != ACT_SIGMOID)
+                                         : (EPI == EPI_DX ? (p.yprev == nullptr || p.act == ACT_RELU) : true);
+    if (m0 + BM <= p.M && n0 + BN <= p.N) {
+        if (simple) write_tile(std::false_type{}, std::true_type{});
+        else write_tile(std::false_type{}, std::false_type{});
+    } else {
+        write_tile(std::true_type{}, std::false_type{});
+    }
+}
 
 template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int EPI, bool GATHER = false>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
@@ -406,72 +561,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
 
     unsigned long long dbg_t1 = 0;
     if (p.dbg & 8) dbg_t1 = __builtin_amdgcn_s_memtime();
-    // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    float* C = p.C + (long long)blockIdx.z * p.c_split_stride;
-    uint32_t key = 0;
-    const bool drop = (EPI == EPI_FWD) && (p.keep < 1.0f);
-    float inv_keep = 1.0f;
-    if (drop) {
-        key = dtf_dropout_key(p.seed, p.step_ptr);
-        inv_keep = 1.0f / p.keep;
-    }
-    // A tile that lies entirely inside C (all of them except the last row / column of tiles) skips the per-element
-    // bounds tests: with them the epilogue is several thousand instructions and costs about a tenth of a short-K GEMM.
-    const float relu_floor = (p.act == ACT_RELU) ? 0.f : -INFINITY;
-    auto write_tile = [&](auto checked, auto simple) {
-        constexpr bool CHECK = decltype(checked)::value;
-        constexpr bool SIMPLE = decltype(simple)::value;   // forward: bias and ReLU / identity only; dgrad: ReLU mask or none
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int col = n0 + (wn * TN + j) * 32 + li;
-                if (CHECK && col >= p.N) continue;
-                float bv = 0.f;
-                if (EPI == EPI_FWD && p.bias) bv = p.bias[col];
-                const int row0 = m0 + (wm * TM + i) * 32 + 4 * h;
-                float* Cp = C + (long long)row0 * p.ldc + col;
-                const float* Yp = (EPI == EPI_DX && p.yprev) ? p.yprev + (long long)row0 * p.ldy + col : nullptr;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int dr = (r & 3) + 8 * (r >> 2);
-                    if (CHECK && row0 + dr >= p.M) continue;
-                    float v = acc[i][j][r];
-                    if (EPI == EPI_FWD) {
-                        v += bv;
-                        if (SIMPLE) {
-                            v = fmaxf(v, relu_floor);
-                        } else {
-                            if (p.act == ACT_SIGMOID) v = dtf_sigmoid(v);
-                            else v = fmaxf(v, relu_floor);
-                            if (drop) {
-                                const float u = dtf_uniform(key, (unsigned long long)(row0 + dr) * (unsigned)p.N + col);
-                                v = (u < p.keep) ? v * inv_keep : 0.f;
-                            }
-                        }
-                    } else if (EPI == EPI_DX) {
-                        if (SIMPLE) {
-                            if (Yp) v = (Yp[(long long)dr * p.ldy] > 0.f) ? v * p.scale_prev : 0.f;
-                        } else if (Yp) {
-                            const float y = Yp[(long long)dr * p.ldy];
-                            if (p.act == ACT_RELU) v = (y > 0.f) ? v * p.scale_prev : 0.f;
-                            else if (p.act == ACT_SIGMOID) v = v * y * (1.0f - y);
-                        }
-                    }
-                    Cp[(long long)dr * p.ldc] = v;
-                }
-            }
-        }
-    };
-    const bool simple = (EPI == EPI_FWD) ? (!drop && p.act != ACT_SIGMOID)
-                                         : (EPI == EPI_DX ? (p.yprev == nullptr || p.act == ACT_RELU) : true);
-    if (m0 + BM <= p.M && n0 + BN <= p.N) {
-        if (simple) write_tile(std::false_type{}, std::true_type{});
-        else write_tile(std::false_type{}, std::false_type{});
-    } else {
-        write_tile(std::true_type{}, std::false_type{});
-    }
+    gemm_epilogue<TM, TN, BM, BN, EPI>(p, acc, m0, n0, wm, wn, li, h);
     if ((p.dbg & 8) && tid == 0) {   // timing-only diagnostic: loop cycles and 100 MHz ticks into the tile's first row
+        float* C = p.C + (long long)blockIdx.z * p.c_split_stride;
         C[(long long)m0 * p.ldc + n0] = (float)(__builtin_amdgcn_s_memtime() - dbg_t0);
         C[(long long)m0 * p.ldc + n0 + 1] = (float)(__builtin_amdgcn_s_memrealtime() - dbg_r0);
         C[(long long)m0 * p.ldc + n0 + 2] = (float)(dbg_t1 - dbg_t0);
@@ -482,6 +574,103 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
         if (do_colsum && tid < BN && (n0 + tid) < p.N)
             p.colsum[(long long)blockIdx.z * p.colsum_split_stride + n0 + tid] = csum;
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// bf16-operand variant for wide layers (opt-in mixed precision): operands are read as fp32, rounded to bf16 on the way
+// into LDS, multiplied on v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate) and accumulated in fp32; outputs, bias,
+// activations, dropout and the optimizer stay fp32.  128x128 tile, four waves of 64x64, 32-deep k tiles (two
+// 16-deep MFMA steps); both LDS images are k-contiguous so every fragment is one 16-byte read: lane (r = lane & 31,
+// h = lane >> 5) holds A[row r][k = 8h .. 8h+7] and B[k = 8h .. 8h+7][col r].
+template <bool A_KC, bool B_KC, int EPI>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs p) {
+    constexpr int BM = 128, BN = 128, TM = 2, TN = 2;
+    using LoadA = typename PickBf16Loader<BM, A_KC>::type;
+    using LoadB = typename PickBf16Loader<BN, B_KC>::type;
+    constexpr int TILE = BM * LDKB;                 // bf16 elements per operand image (BM == BN)
+    __shared__ __attribute__((aligned(16))) unsigned short smem[2 * 2 * TILE];   // two stages of [A | B]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = blockIdx.z * p.k_chunk;
+    const int kend = min(p.K, kbeg + p.k_chunk);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    LoadA la;
+    LoadB lb;
+    la.init(p.A, p.lda, m0, p.M, kbeg, p.K);
+    lb.init(p.B, p.ldb, n0, p.N, kbeg, p.K);
+    la.load(kbeg, kbeg, kend - kbeg, tid);
+    lb.load(kbeg, kbeg, kend - kbeg, tid);
+    la.store_bf16(smem, kend - kbeg, tid);
+    lb.store_bf16(smem + TILE, kend - kbeg, tid);
+    __syncthreads();
+
+    int stage = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        const bool more = (k0 + BK) < kend;
+        const unsigned short* As = smem + stage * 2 * TILE;
+        const unsigned short* Bs = As + TILE;
+        if (more) {
+            la.load(k0 + BK, kbeg, kend - k0 - BK, tid);
+            lb.load(k0 + BK, kbeg, kend - k0 - BK, tid);
+        }
+        bf16x8 a[2][TM], b[2][TN];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                a[ks][i] = *reinterpret_cast<const bf16x8*>(As + ((wm * TM + i) * 32 + li) * LDKB + ks * 16 + 8 * h);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                b[ks][j] = *reinterpret_cast<const bf16x8*>(Bs + ((wn * TN + j) * 32 + li) * LDKB + ks * 16 + 8 * h);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
+        if (more) {
+            unsigned short* nx = smem + (stage ^ 1) * 2 * TILE;
+            la.store_bf16(nx, kend - k0 - BK, tid);
+            lb.store_bf16(nx + TILE, kend - k0 - BK, tid);
+        }
+        __syncthreads();
+        stage ^= 1;
+    }
+    gemm_epilogue<TM, TN, BM, BN, EPI>(p, acc, m0, n0, wm, wn, li, h);
+}
+
+template <bool A_KC, bool B_KC, int EPI>
+int launch_bf16(const GemmArgs& a, hipStream_t s) {
+    dim3 grid((a.N + 127) / 128, (a.M + 127) / 128, 1);
+    hipLaunchKernelGGL((gemm_bf16_kernel<A_KC, B_KC, EPI>), grid, dim3(256), 0, s, a);
+    DTF_CHECK_LAUNCH();
+    return 0;
+}
+
+// db[n] = sum over m of dZ[m][n]: one thread per 4 columns and row block, row blocks meet through atomics on a zeroed db
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ dZ, float* __restrict__ db, int M, int N,
+                                                     int rows_per_block) {
+    const int c4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (c4 >= N) return;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f};
+    for (int r = r0; r < r1; ++r) s0 += *reinterpret_cast<const f32x4*>(dZ + (long long)r * N + c4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) atomicAdd(db + c4 + e, s0[e]);
 }
 
 inline int env_dbg() {
@@ -882,5 +1071,57 @@ DTF_API int dtf_conv_gemm_wgrad(const float* Xpad, long long xpad_elems, const i
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3((int)((n_total + 255) / 256)), dim3(1024), 0, stream, workspace, stride,
                        eff_splits, dW, kn, db, n_total);
     DTF_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// bf16-operand products (see gemm_bf16_kernel).  Shapes must give the kernel whole float4 vectors; products too small
+// to fill the chip with 128x128 tiles are refused (-5) and the caller stays on the fp32 kernels.
+static bool bf16_shape_ok(long long rows, long long cols, int k) {
+    return cols % 4 == 0 && k % 4 == 0 && ((rows + 127) / 128) * ((cols + 127) / 128) >= 128;
+}
+
+DTF_API int dtf_dense_bf16_supported(int M, int N, int K) {
+    return (bf16_shape_ok(M, N, K) && bf16_shape_ok(M, K, N) && bf16_shape_ok(K, N, M)) ? 1 : 0;
+}
+
+DTF_API int dtf_dense_fwd_bf16(const float* X, const float* W, const float* bias, float* Y, int M, int N, int K, int act,
+                               float keep, uint32_t seed, const long long* step_ptr, hipStream_t stream) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    if (!bf16_shape_ok(M, N, K)) return -5;
+    GemmArgs a = {};
+    a.A = X; a.lda = K; a.B = W; a.ldb = N; a.C = Y; a.ldc = N;
+    a.M = M; a.N = N; a.K = K; a.k_chunk = ((K + BK - 1) / BK) * BK;
+    a.bias = bias; a.act = act; a.keep = keep; a.seed = seed; a.step_ptr = step_ptr;
+    return launch_bf16<true, false, EPI_FWD>(a, stream);
+}
+
+DTF_API int dtf_dense_bwd_dx_bf16(const float* dZ, const float* W, float* dX, int M, int N, int K, const float* Yprev,
+                                  int act_prev, float scale_prev, hipStream_t stream) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    if (!bf16_shape_ok(M, K, N)) return -5;
+    GemmArgs a = {};
+    a.A = dZ; a.lda = N; a.B = W; a.ldb = N; a.C = dX; a.ldc = K;
+    a.M = M; a.N = K; a.K = N; a.k_chunk = ((N + BK - 1) / BK) * BK;
+    a.yprev = Yprev; a.ldy = K; a.act = act_prev; a.scale_prev = scale_prev;
+    return launch_bf16<true, true, EPI_DX>(a, stream);
+}
+
+DTF_API int dtf_dense_bwd_dw_bf16(const float* X, const float* dZ, float* dW, float* db, int M, int N, int K,
+                                  hipStream_t stream) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    if (!bf16_shape_ok(K, N, M)) return -5;
+    GemmArgs a = {};
+    a.A = X; a.lda = K; a.B = dZ; a.ldb = N; a.C = dW; a.ldc = N;
+    a.M = K; a.N = N; a.K = M; a.k_chunk = ((M + BK - 1) / BK) * BK;
+    int rc = launch_bf16<false, false, EPI_DW>(a, stream);
+    if (rc) return rc;
+    if (db) {                                        // the bias gradient stays an fp32 sum of the unrounded dZ
+        if (hipMemsetAsync(db, 0, (size_t)N * sizeof(float), stream) != hipSuccess) return -6;
+        const int rows_per_block = 256;
+        dim3 grid((N / 4 + 255) / 256, (M + rows_per_block - 1) / rows_per_block);
+        hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, stream, dZ, db, M, N, rows_per_block);
+        DTF_CHECK_LAUNCH();
+    }
     return 0;
 }

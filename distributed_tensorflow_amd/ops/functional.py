@@ -73,6 +73,17 @@ def _apply_act(z: torch.Tensor, act: int) -> torch.Tensor:
     return z
 
 
+def dense_bf16_supported(M: int, N: int, K: int) -> bool:
+    """True when all three products of a [M,K] x [K,N] dense layer can run on the bf16-operand MFMA kernels (wide
+    layers: at least 128 output tiles of 128x128 each way)."""
+    return nv.kernels_available() and bool(nv.kernels().dtf_dense_bf16_supported(M, N, K))
+
+
+def _bf16_round(t: torch.Tensor) -> torch.Tensor:
+    """fp32 values rounded to bf16 (nearest even), as the bf16-operand kernels round their operands."""
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
 def dense_fwd_workspace_floats(M: int, N: int, K: int) -> int:
     """Floats of scratch with which ``dense_forward`` may split a long K (few output tiles); 0 = never splits."""
     if not nv.kernels_available():
@@ -81,8 +92,10 @@ def dense_fwd_workspace_floats(M: int, N: int, K: int) -> int:
     return s * M * N if s > 1 else 0
 
 
-def dense_forward(x, w, b=None, act=ACT_NONE, keep=1.0, seed=0, step=None, out=None, workspace=None):
-    """``dropout(act(x @ w + b))`` with inverted dropout (keep probability ``keep``)."""
+def dense_forward(x, w, b=None, act=ACT_NONE, keep=1.0, seed=0, step=None, out=None, workspace=None, bf16=False):
+    """``dropout(act(x @ w + b))`` with inverted dropout (keep probability ``keep``).
+
+    ``bf16=True``: both operands are rounded to bf16 for the product (fp32 accumulation, fp32 everything else)."""
     M, K = x.shape
     K2, N = w.shape
     assert K == K2, "x[%d,%d] @ w[%d,%d]" % (M, K, K2, N)
@@ -92,7 +105,10 @@ def dense_forward(x, w, b=None, act=ACT_NONE, keep=1.0, seed=0, step=None, out=N
         nv.require_f32_contig(x, w, b, out)
         if step is not None:
             assert step.dtype == torch.int64 and step.is_cuda
-        if workspace is not None:
+        if bf16:
+            rc = nv.kernels().dtf_dense_fwd_bf16(nv.ptr(x), nv.ptr(w), nv.ptr(b), nv.ptr(out), M, N, K, int(act),
+                                                 float(keep), int(seed) & _M32, nv.ptr(step), nv.stream_ptr())
+        elif workspace is not None:
             rc = nv.kernels().dtf_dense_fwd_ws(nv.ptr(x), nv.ptr(w), nv.ptr(b), nv.ptr(out), M, N, K, int(act),
                                                float(keep), int(seed) & _M32, nv.ptr(step), nv.ptr(workspace),
                                                workspace.numel(), nv.stream_ptr())
@@ -101,7 +117,7 @@ def dense_forward(x, w, b=None, act=ACT_NONE, keep=1.0, seed=0, step=None, out=N
                                             float(keep), int(seed) & _M32, nv.ptr(step), nv.stream_ptr())
         nv.check(rc, "dtf_dense_fwd")
         return out
-    z = x @ w
+    z = _bf16_round(x) @ _bf16_round(w) if bf16 else x @ w
     if b is not None:
         z = z + b
     y = _apply_act(z, act)
@@ -112,7 +128,7 @@ def dense_forward(x, w, b=None, act=ACT_NONE, keep=1.0, seed=0, step=None, out=N
     return out
 
 
-def dense_backward_dx(dz, w, yprev=None, act_prev=ACT_NONE, scale_prev=1.0, out=None):
+def dense_backward_dx(dz, w, yprev=None, act_prev=ACT_NONE, scale_prev=1.0, out=None, bf16=False):
     """``dz @ w.T`` followed by the producing layer's activation/dropout gradient.
 
     ``yprev`` is the producing layer's OUTPUT (this layer's input).  relu(+dropout):
@@ -125,11 +141,12 @@ def dense_backward_dx(dz, w, yprev=None, act_prev=ACT_NONE, scale_prev=1.0, out=
         out = torch.empty((M, K), dtype=torch.float32, device=dz.device)
     if dz.is_cuda:
         nv.require_f32_contig(dz, w, yprev, out)
-        rc = nv.kernels().dtf_dense_bwd_dx(nv.ptr(dz), nv.ptr(w), nv.ptr(out), M, N, K, nv.ptr(yprev),
-                                           int(act_prev), float(scale_prev), nv.stream_ptr())
+        fn = nv.kernels().dtf_dense_bwd_dx_bf16 if bf16 else nv.kernels().dtf_dense_bwd_dx
+        rc = fn(nv.ptr(dz), nv.ptr(w), nv.ptr(out), M, N, K, nv.ptr(yprev), int(act_prev), float(scale_prev),
+                nv.stream_ptr())
         nv.check(rc, "dtf_dense_bwd_dx")
         return out
-    dx = dz @ w.t()
+    dx = _bf16_round(dz) @ _bf16_round(w).t() if bf16 else dz @ w.t()
     if yprev is not None:
         if act_prev == ACT_RELU:
             dx = torch.where(yprev > 0, dx * scale_prev, torch.zeros_like(dx))
@@ -147,13 +164,17 @@ def dense_dw_workspace_floats(M: int, N: int, K: int) -> int:
     return s * ((K * N + N + 3) // 4 * 4) if s > 1 else 0
 
 
-def dense_backward_dw(x, dz, dw, db=None, workspace=None):
+def dense_backward_dw(x, dz, dw, db=None, workspace=None, bf16=False):
     """``dw = x.T @ dz`` and ``db = dz.sum(0)`` written into the given (flat-buffer) views."""
     M, K = x.shape
     M2, N = dz.shape
     assert M == M2 and tuple(dw.shape) == (K, N)
     if x.is_cuda:
         nv.require_f32_contig(x, dz, dw, db)
+        if bf16:
+            rc = nv.kernels().dtf_dense_bwd_dw_bf16(nv.ptr(x), nv.ptr(dz), nv.ptr(dw), nv.ptr(db), M, N, K, nv.stream_ptr())
+            nv.check(rc, "dtf_dense_bwd_dw_bf16")
+            return dw, db
         need = dense_dw_workspace_floats(M, N, K)
         if need and (workspace is None or workspace.numel() < need):
             workspace = torch.empty(need, dtype=torch.float32, device=x.device)
@@ -161,7 +182,7 @@ def dense_backward_dw(x, dz, dw, db=None, workspace=None):
                                            nv.ptr(workspace), nv.stream_ptr())
         nv.check(rc, "dtf_dense_bwd_dw")
         return dw, db
-    dw.copy_(x.t() @ dz)
+    dw.copy_(_bf16_round(x).t() @ _bf16_round(dz) if bf16 else x.t() @ dz)
     if db is not None:
         db.copy_(dz.sum(0))
     return dw, db
