@@ -51,6 +51,9 @@ def parse_args():
                     help="testing aid: run the multi-GPU code path (RCCL calls included) on a 1-rank process group")
     ap.add_argument("--allreduce", default="rccl", choices=["rccl", "p2p"],
                     help="small-model gradient exchange: RCCL all-reduce, or the one-shot peer-pointer kernel (one node)")
+    ap.add_argument("--matmul", default="fp32", choices=["fp32", "bf16"],
+                    help="bf16: opt-in mixed precision for wide dense layers (bf16 operands, fp32 accumulation); the "
+                         "headline numbers are fp32")
     ap.add_argument("--eval", type=int, default=0, help="also train for this many extra steps and report test accuracy")
     return ap.parse_args()
 
@@ -123,7 +126,8 @@ def main():
         model = models.wide_mlp(width=args.width, depth=args.depth)
         loss = "sparse_categorical_crossentropy"
         make = lambda n, seed: data.mnist_like(n, seed=seed, device=dev)
-    model.compile(loss=loss, optimizer="adam", metrics=["accuracy"], strategy=strategy, device=dev, seed=0)
+    model.compile(loss=loss, optimizer="adam", metrics=["accuracy"], strategy=strategy, device=dev, seed=0,
+                  matmul_dtype=args.matmul)
 
     pool = max(1, args.pool)
     # small-batch reference network on one GPU: the whole step (and runs of consecutive steps) is one launch
@@ -222,7 +226,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": value / BASELINE_EXAMPLES_PER_SEC,
-            "dtype": "fp32",
+            "dtype": "fp32" if args.matmul == "fp32" else "bf16 operands / fp32 accumulate (wide dense layers), fp32 elsewhere",
             "data": "synthetic (device-resident MNIST-shaped inputs, random-init weights)",
             "config": {"model": args.model, "global_batch": global_batch, "batch_per_gpu": B, "seq_len": None,
                        "parallelism": ("dp%d" if args.mode == "sync" else "async-ps%d") % world, "params": model.store.num_params,

@@ -149,12 +149,16 @@ class Dense(Layer):
         keep = self.fused_keep if training else 1.0
         y = self._buf.get("y", (M, self.units), x.device)
         ws = None
-        if x.is_cuda:
+        # opt-in mixed precision (compile(matmul_dtype="bf16")): wide layers multiply bf16-rounded operands
+        bf16 = getattr(self, "matmul_dtype", "fp32") == "bf16" and x.is_cuda and \
+            F.dense_bf16_supported(M, self.units, x.shape[1])
+        self._bf16_used = bf16
+        if x.is_cuda and not bf16:
             need = F.dense_fwd_workspace_floats(M, self.units, x.shape[1])      # long K, few output tiles: K is split
             if need:
                 ws = self._buf.get("fwd_ws", (need,), x.device)
         F.dense_forward(x, self.kernel.tensor, self.bias.tensor if self.bias is not None else None, self.act,
-                        keep, self.seed, self.store.global_step, out=y, workspace=ws)
+                        keep, self.seed, self.store.global_step, out=y, workspace=ws, bf16=bf16)
         self._x, self._y, self._keep_used = x, y, keep
         if self.softmax and not self.emit_logits:
             # probabilities are only materialised when no fused cross-entropy consumes the logits
@@ -184,13 +188,14 @@ class Dense(Layer):
                 self._ws = (M, torch.empty(need, dtype=torch.float32, device=x.device))
             else:
                 self._ws = (M, self._ws[1])
+        bf16 = getattr(self, "_bf16_used", False)
         F.dense_backward_dw(x, dz, self.kernel.grad, self.bias.grad if self.bias is not None else None,
-                            workspace=self._ws[1])
+                            workspace=self._ws[1], bf16=bf16)
         if not self.need_input_grad:
             return None
         dx = self._buf.get("dx", x.shape, x.device)
         F.dense_backward_dx(dz, self.kernel.tensor, x if self.fuse_prev_grad else None, self.prev_act,
-                            self.prev_scale, out=dx)
+                            self.prev_scale, out=dx, bf16=bf16)
         return dx
 
 

@@ -142,7 +142,16 @@ class Sequential:
 
     # ------------------------------------------------------------------ compile
     def compile(self, loss="mean_squared_error", optimizer="adam", metrics: Optional[Sequence[str]] = None,
-                strategy=None, device=None, seed: Optional[int] = None):
+                strategy=None, device=None, seed: Optional[int] = None, matmul_dtype: str = "fp32"):
+        """``matmul_dtype="bf16"`` (opt-in mixed precision): dense layers wide enough for the bf16-operand MFMA
+        kernels multiply bf16-rounded operands with fp32 accumulation; variables, gradients, optimizer state and all
+        narrow layers stay fp32, as in the reference (/root/reference/example.py:149,155: tf.float32 throughout)."""
+        if matmul_dtype not in ("fp32", "bf16"):
+            raise ValueError("matmul_dtype must be 'fp32' or 'bf16'")
+        self.matmul_dtype = matmul_dtype
+        for l in self.layers:
+            if isinstance(l, Dense):
+                l.matmul_dtype = matmul_dtype
         self.loss = losses_mod.get(loss)
         self.optimizer = optim_mod.get(optimizer)
         self.metrics = list(metrics or [])

@@ -56,3 +56,32 @@ def test_small_layers_are_refused(gpu_device):
     w = torch.zeros(64, 128, device=gpu_device)
     with pytest.raises(Exception):
         F.dense_forward(x, w, None, 0, bf16=True)
+
+
+def test_wide_model_trains_in_mixed_precision(gpu_device):
+    """compile(matmul_dtype="bf16"): the wide layers run on the bf16 kernels, gradients stay close to the fp32 run's
+    and the loss goes down."""
+    from distributed_tensorflow_amd import models
+    from distributed_tensorflow_amd.data import mnist_like
+    x, y = mnist_like(2048, seed=0, device=gpu_device)
+    grads, losses = {}, {}
+    for dt in ("fp32", "bf16"):
+        m = models.wide_mlp(width=2048, depth=3)
+        m.compile(loss="sparse_categorical_crossentropy", optimizer="sgd", metrics=["accuracy"], device=gpu_device, seed=4,
+                  matmul_dtype=dt)
+        m.stats.zero_()
+        m.train_step(x, y)
+        grads[dt] = m.store.flat_grad.clone()
+        used = [getattr(l, "_bf16_used", False) for l in m.layers if hasattr(l, "units")]
+        assert any(used) == (dt == "bf16") and not used[-1]          # the 10-unit head is never a bf16 product
+        ls = []
+        for _ in range(15):
+            m.stats.zero_()
+            m.train_step(x, y)
+            ls.append(m.read_stats()["loss"])
+        losses[dt] = ls
+    cos = torch.nn.functional.cosine_similarity(grads["fp32"], grads["bf16"], dim=0)
+    assert cos > 0.995, cos
+    assert not torch.equal(grads["fp32"], grads["bf16"])
+    assert losses["bf16"][-1] < losses["bf16"][0]
+    assert abs(losses["bf16"][-1] - losses["fp32"][-1]) < 0.1 * abs(losses["fp32"][0])
