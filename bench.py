@@ -51,9 +51,10 @@ def parse_args():
                     help="testing aid: run the multi-GPU code path (RCCL calls included) on a 1-rank process group")
     ap.add_argument("--allreduce", default="rccl", choices=["rccl", "p2p"],
                     help="small-model gradient exchange: RCCL all-reduce, or the one-shot peer-pointer kernel (one node)")
-    ap.add_argument("--matmul", default="fp32", choices=["fp32", "bf16"],
-                    help="bf16: opt-in mixed precision for wide dense layers (bf16 operands, fp32 accumulation); the "
-                         "headline numbers are fp32")
+    ap.add_argument("--matmul", default="fp32", choices=["fp32", "fp32_split", "bf16"],
+                    help="fp32 (default): fp32 MFMA.  fp32_split: fp32 operands split exactly into three bf16 limbs, six "
+                         "limb products accumulated in fp32 on the bf16 matrix cores (fp32-level accuracy).  bf16: opt-in "
+                         "mixed precision for wide dense layers (bf16 operands, fp32 accumulation)")
     ap.add_argument("--eval", type=int, default=0, help="also train for this many extra steps and report test accuracy")
     return ap.parse_args()
 
@@ -226,7 +227,8 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": value / BASELINE_EXAMPLES_PER_SEC,
-            "dtype": "fp32" if args.matmul == "fp32" else "bf16 operands / fp32 accumulate (wide dense layers), fp32 elsewhere",
+            "dtype": {"fp32": "fp32", "fp32_split": "fp32 (operands as three bf16 limbs, fp32 accumulate, fp32-level accuracy)",
+                      "bf16": "bf16 operands / fp32 accumulate (wide dense layers), fp32 elsewhere"}[args.matmul],
             "data": "synthetic (device-resident MNIST-shaped inputs, random-init weights)",
             "config": {"model": args.model, "global_batch": global_batch, "batch_per_gpu": B, "seq_len": None,
                        "parallelism": ("dp%d" if args.mode == "sync" else "async-ps%d") % world, "params": model.store.num_params,

@@ -81,6 +81,16 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, l
 
 constexpr unsigned OOB = 0xFFFFFFF8u;  // >= any num_records: the load returns zeros
 
+// Exact split of an fp32 value into three bf16 limbs, x = hi + mid + lo: each limb is the bf16 rounding of what the
+// previous limbs left over, and both subtractions are exact in fp32 (3 x 8 significant bits cover the 24 of fp32).
+__device__ __forceinline__ void split3(float x, __bf16& hi, __bf16& mid, __bf16& lo) {
+    hi = (__bf16)x;
+    float r = x - (float)hi;
+    mid = (__bf16)r;
+    r -= (float)mid;
+    lo = (__bf16)r;
+}
+
 // Tile of ROWS (M- or N-dim) x BK (k-dim) held by 256 threads as NV float4 each.
 //   KC  (k is the contiguous global dim): LDS image [ROWS][LDK]
 //   !KC (the M/N index is contiguous)   : LDS image [BK][ROWS+4]
@@ -199,6 +209,26 @@ struct TileLoader {
             }
         }
     }
+
+    // Three bf16 limb planes (hi | mid | lo, `plane` elements apart) of a k-contiguous tile whose K is a multiple of 4.
+    __device__ __forceinline__ void store_split(unsigned short* lds, int plane, int tid) const {
+        static_assert(KC, "M/N-contiguous operands go through TransposeLoader");
+#pragma unroll
+        for (int s = 0; s < NV; ++s) {
+            const int id = tid + 256 * s;
+            bf16x4 hi, mid, lo;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                __bf16 a, b, c;
+                split3(v[s][j], a, b, c);
+                hi[j] = a; mid[j] = b; lo[j] = c;
+            }
+            unsigned short* d = lds + (id >> 3) * LDKB + (id & 7) * 4;
+            *reinterpret_cast<bf16x4*>(d) = hi;
+            *reinterpret_cast<bf16x4*>(d + plane) = mid;
+            *reinterpret_cast<bf16x4*>(d + 2 * plane) = lo;
+        }
+    }
 };
 
 // Loader of an M/N-contiguous operand for the bf16 kernel.  The LDS image must be k-contiguous, so the tile is
@@ -243,6 +273,30 @@ struct TransposeLoader {
             for (int s = 0; s < NV; ++s) y[s] = (__bf16)((j == 0 || j < lim) ? v[s][j] : 0.f);
             *reinterpret_cast<bf16x4*>(lds + (r + j) * LDKB + c0) = y;
         }
+    }
+    // limb planes as in TileLoader::store_split; the M/N extent is a multiple of 4, so a loaded vector is all inside
+    // the operand or all zeros
+    __device__ __forceinline__ void store_split(unsigned short* lds, int plane, int tid) const {
+        const int r = (tid & 31) * 4, c0 = (tid >> 5) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bf16x4 hi, mid, lo;
+#pragma unroll
+            for (int s = 0; s < NV; ++s) {
+                __bf16 a, b, c;
+                split3(v[s][j], a, b, c);
+                hi[s] = a; mid[s] = b; lo[s] = c;
+            }
+            unsigned short* d = lds + (r + j) * LDKB + c0;
+            *reinterpret_cast<bf16x4*>(d) = hi;
+            *reinterpret_cast<bf16x4*>(d + plane) = mid;
+            *reinterpret_cast<bf16x4*>(d + 2 * plane) = lo;
+        }
+    }
+    // column sums of the tile this thread holds (columns r .. r+3 over its 4 k rows)
+    __device__ __forceinline__ void add_colsum(f32x4& cs) const {
+#pragma unroll
+        for (int s = 0; s < NV; ++s) cs += v[s];
     }
 };
 
@@ -661,6 +715,150 @@ int launch_bf16(const GemmArgs& a, hipStream_t s) {
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// fp32 products on the bf16 matrix cores.  gfx950 multiplies bf16 sixteen times faster than fp32, so each fp32 operand
+// element is split EXACTLY into three bf16 limbs on its way into LDS (split3) and the product is accumulated in fp32
+// from the partial products of the limbs, most significant last:
+//     hi.hi, hi.mid, mid.hi, mid.mid, hi.lo, lo.hi, mid.lo, lo.mid   (NPROD = 8; lo.lo, 2^-32 of a product, is dropped;
+//                                                                    NPROD = 6 also drops the two 2^-24 terms)
+// Every partial product of two bf16 values is exact in the fp32 accumulator's input, so the result differs from an
+// fp32 FMA chain only in rounding order (measured against fp64: the same or a smaller error than the fp32 MFMA
+// kernel's, for 6, 8 and 9 products alike).  128x128 tile, four waves of 64x64, one 32-deep k tile in LDS as six
+// [128][LDKB] limb planes (60 KB: two blocks per CU); the next tile's global loads fly during the MFMAs.
+// The chip is power-limited here: with random operands the MFMA phase alone runs at ~1.6 GHz (4430 cycles per k tile
+// and block pair, 92 % of the pipe), the split phase at ~2.3 GHz, and their times add up whether or not the two
+// resident blocks are staggered - so fewer limb products, not more overlap, is what buys time
+// (DTF_GEMM_DBG bits 8 / 4 / 16 with bench/gemm_split_probe.py measure the phases).
+template <bool A_KC, bool B_KC, int EPI, int NPROD>
+__global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const GemmArgs p) {
+    constexpr int BM = 128, BN = 128, TM = 2, TN = 2;
+    using LoadA = typename PickBf16Loader<BM, A_KC>::type;
+    using LoadB = typename PickBf16Loader<BN, B_KC>::type;
+    constexpr int TILE = BM * LDKB;                 // bf16 elements per limb plane (BM == BN)
+    __shared__ __attribute__((aligned(16))) unsigned short smem[6 * TILE];   // A hi|mid|lo, B hi|mid|lo
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = blockIdx.z * p.k_chunk;
+    const int kend = min(p.K, kbeg + p.k_chunk);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    constexpr bool CAN_COLSUM = (EPI == EPI_DW) && !B_KC;
+    const bool do_colsum = CAN_COLSUM && p.colsum != nullptr && blockIdx.y == 0;
+    f32x4 cs = {0.f, 0.f, 0.f, 0.f};
+
+    LoadA la;
+    LoadB lb;
+    la.init(p.A, p.lda, m0, p.M, kbeg, p.K);
+    lb.init(p.B, p.ldb, n0, p.N, kbeg, p.K);
+    la.load(kbeg, kbeg, kend - kbeg, tid);
+    lb.load(kbeg, kbeg, kend - kbeg, tid);
+    unsigned long long dbg_t0 = 0, dbg_r0 = 0;
+    if (p.dbg & 8) { dbg_t0 = __builtin_amdgcn_s_memtime(); dbg_r0 = __builtin_amdgcn_s_memrealtime(); }
+
+    // limb pairs in order of significance
+    constexpr int PA[9] = {0, 0, 1, 1, 0, 2, 1, 2, 2};
+    constexpr int PB[9] = {0, 1, 0, 1, 2, 0, 2, 1, 2};
+
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        if (!(p.dbg & 4) || k0 == kbeg) {
+        la.store_split(smem, TILE, tid);
+        lb.store_split(smem + 3 * TILE, TILE, tid);
+        }
+        if constexpr (CAN_COLSUM) {
+            if (do_colsum) lb.add_colsum(cs);
+        }
+        __syncthreads();
+        if (k0 + BK < kend) {
+            la.load(k0 + BK, kbeg, kend - k0 - BK, tid);
+            lb.load(k0 + BK, kbeg, kend - k0 - BK, tid);
+        }
+        if (!(p.dbg & 16))
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a[3][TM], b[3][TN];
+#pragma unroll
+            for (int l = 0; l < 3; ++l) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    a[l][i] = *reinterpret_cast<const bf16x8*>(smem + l * TILE + ((wm * TM + i) * 32 + li) * LDKB + ks * 16 + 8 * h);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    b[l][j] = *reinterpret_cast<const bf16x8*>(smem + (3 + l) * TILE + ((wn * TN + j) * 32 + li) * LDKB + ks * 16 + 8 * h);
+            }
+#pragma unroll
+            for (int q = NPROD - 1; q >= 0; --q)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]][i], b[PB[q]][j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    if constexpr (CAN_COLSUM) {
+        if (do_colsum) {         // uniform per block; the 8 k-row groups of a column meet in LDS (free after the last barrier)
+            float* red = reinterpret_cast<float*>(smem);
+            *reinterpret_cast<f32x4*>(red + (tid >> 5) * BN + (tid & 31) * 4) = cs;
+            __syncthreads();
+            if (tid < BN && n0 + tid < p.N) {
+                float t = 0.f;
+#pragma unroll
+                for (int g = 0; g < 8; ++g) t += red[g * BN + tid];
+                p.colsum[(long long)blockIdx.z * p.colsum_split_stride + n0 + tid] = t;
+            }
+        }
+    }
+    gemm_epilogue<TM, TN, BM, BN, EPI>(p, acc, m0, n0, wm, wn, li, h);
+    if ((p.dbg & 8) && tid == 0) {   // timing-only diagnostic: block cycles and 100 MHz ticks over the tile's first outputs
+        float* C = p.C + (long long)blockIdx.z * p.c_split_stride;
+        C[(long long)m0 * p.ldc + n0] = (float)(__builtin_amdgcn_s_memtime() - dbg_t0);
+        C[(long long)m0 * p.ldc + n0 + 1] = (float)(__builtin_amdgcn_s_memrealtime() - dbg_r0);
+    }
+}
+
+inline int env_dbg();
+
+// Number of limb products the fp32 GEMMs use on the bf16 matrix cores; 0 = native fp32 MFMA (the default).
+int g_split_products = -1;
+inline int split_products() {
+    if (g_split_products < 0) {
+        const char* e = getenv("DTF_GEMM_SPLIT");
+        const int v = e ? atoi(e) : 0;
+        g_split_products = (v == 6 || v == 8 || v == 9) ? v : 0;
+    }
+    return g_split_products;
+}
+
+// the split kernel wants whole float4 vectors on every operand and enough 128x128 tiles to be worth its 60 KB blocks
+inline bool split_shape_ok(const GemmArgs& a, int splits) {
+    if (((a.M | a.N | a.K | a.lda | a.ldb | a.k_chunk) & 3) != 0) return false;
+    if (a.M < 64 || a.N < 64) return false;
+    return (long long)((a.M + 127) / 128) * ((a.N + 127) / 128) * splits >= 64;
+}
+
+template <bool A_KC, bool B_KC, int EPI>
+int launch_x3(const GemmArgs& a, int splits, int nprod, hipStream_t s) {
+    dim3 grid((a.N + 127) / 128, (a.M + 127) / 128, splits);
+    GemmArgs args = a;
+    args.dbg = env_dbg();
+    if (nprod == 6) hipLaunchKernelGGL((gemm_x3_kernel<A_KC, B_KC, EPI, 6>), grid, dim3(256), 0, s, args);
+    else if (nprod == 9) hipLaunchKernelGGL((gemm_x3_kernel<A_KC, B_KC, EPI, 9>), grid, dim3(256), 0, s, args);
+    else hipLaunchKernelGGL((gemm_x3_kernel<A_KC, B_KC, EPI, 8>), grid, dim3(256), 0, s, args);
+    DTF_CHECK_LAUNCH();
+    return 0;
+}
+
 // db[n] = sum over m of dZ[m][n]: one thread per 4 columns and row block, row blocks meet through atomics on a zeroed db
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ dZ, float* __restrict__ db, int M, int N,
                                                      int rows_per_block) {
@@ -758,6 +956,9 @@ inline int env_tile() {
 
 template <bool A_KC, bool B_KC, int EPI, bool GATHER>
 int launch_tiled(const GemmArgs& a, int splits, hipStream_t s, int tile_hint) {
+    if constexpr (!GATHER) {
+        if (split_products() && split_shape_ok(a, splits)) return launch_x3<A_KC, B_KC, EPI>(a, splits, split_products(), s);
+    }
     if (a.N <= 32) return launch_cfg<128, 32, 4, 1, A_KC, B_KC, EPI, GATHER>(a, splits, s);
     int t = tile_hint;
     if (a.N <= 64 || a.M <= 64) t = 64;
@@ -827,6 +1028,11 @@ __global__ __launch_bounds__(1024) void reduce_slabs_kernel(const float* __restr
 }
 
 }  // namespace
+
+// 0: fp32 GEMMs on the fp32 MFMA (default); 6 / 8 / 9: on the bf16 matrix cores from that many limb products
+// (gemm_x3_kernel).  Workspace sizes depend on it: set it before querying dtf_dense_bwd_dw_splits.
+DTF_API void dtf_gemm_set_split_products(int n) { g_split_products = (n == 6 || n == 8 || n == 9) ? n : 0; }
+DTF_API int dtf_gemm_get_split_products() { return split_products(); }
 
 // Y = dropout(act(X.W + b)).  keep >= 1 disables dropout.
 DTF_API int dtf_dense_fwd(const float* X, const float* W, const float* bias, float* Y, int M, int N, int K,
@@ -934,6 +1140,12 @@ static DwPlan dw_plan(int M, int N, int K) {
     }
     int max_by_m = (M + 8 * BK - 1) / (8 * BK);      // at least 256 rows of batch per split
     if (max_by_m < 1) max_by_m = 1;
+    if (split_products() && ((M | N | K) & 3) == 0 && N >= 64 && K >= 64) {     // split kernel: 128x128 only, 2 blocks per CU
+        const int tiles = ((K + 127) / 128) * ((N + 127) / 128);
+        int want = 512 / tiles;
+        if (want < 1) want = 1;
+        return {128, want < max_by_m ? want : max_by_m};
+    }
     if (N <= 32) {
         const int tiles = ((K + 127) / 128) * ((N + 31) / 32);
         int want = 512 / tiles;

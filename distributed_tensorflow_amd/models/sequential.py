@@ -145,10 +145,19 @@ class Sequential:
                 strategy=None, device=None, seed: Optional[int] = None, matmul_dtype: str = "fp32"):
         """``matmul_dtype="bf16"`` (opt-in mixed precision): dense layers wide enough for the bf16-operand MFMA
         kernels multiply bf16-rounded operands with fp32 accumulation; variables, gradients, optimizer state and all
-        narrow layers stay fp32, as in the reference (/root/reference/example.py:149,155: tf.float32 throughout)."""
-        if matmul_dtype not in ("fp32", "bf16"):
-            raise ValueError("matmul_dtype must be 'fp32' or 'bf16'")
+        narrow layers stay fp32, as in the reference (/root/reference/example.py:149,155: tf.float32 throughout).
+        ``matmul_dtype="fp32_split"`` keeps fp32 accuracy but multiplies on the bf16 matrix cores: every dense-layer
+        GEMM large enough splits its fp32 operands exactly into three bf16 limbs and accumulates six limb products
+        in fp32 (process-wide switch, see ``ops.functional.set_gemm_split_products``; DTF_GEMM_SPLIT=8 or 9 adds the
+        2^-24 / 2^-32 terms)."""
+        if matmul_dtype not in ("fp32", "bf16", "fp32_split"):
+            raise ValueError("matmul_dtype must be 'fp32', 'fp32_split' or 'bf16'")
         self.matmul_dtype = matmul_dtype
+        if matmul_dtype == "fp32_split":
+            import os as _os
+            F.set_gemm_split_products(int(_os.environ.get("DTF_GEMM_SPLIT", "6")))
+        else:
+            F.set_gemm_split_products(0)
         for l in self.layers:
             if isinstance(l, Dense):
                 l.matmul_dtype = matmul_dtype

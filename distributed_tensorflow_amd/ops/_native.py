@@ -55,6 +55,8 @@ def kernels():
         "dtf_dense_fwd_ws": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_u32, c_p, c_p, c_ll, c_p],
         "dtf_dense_fwd_splits": [c_i, c_i, c_i],
         "dtf_dense_bf16_supported": [c_i, c_i, c_i],
+        "dtf_gemm_set_split_products": [c_i],
+        "dtf_gemm_get_split_products": [],
         "dtf_dense_fwd_bf16": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_u32, c_p, c_p],
         "dtf_dense_bwd_dx_bf16": [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_f, c_p],
         "dtf_dense_bwd_dw_bf16": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],

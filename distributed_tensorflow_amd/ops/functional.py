@@ -79,6 +79,19 @@ def dense_bf16_supported(M: int, N: int, K: int) -> bool:
     return nv.kernels_available() and bool(nv.kernels().dtf_dense_bf16_supported(M, N, K))
 
 
+def set_gemm_split_products(n: int) -> None:
+    """Process-wide switch of the fp32 dense GEMMs: 0 (default) multiplies on the fp32 MFMA; 6, 8 or 9 splits every
+    fp32 operand exactly into three bf16 limbs and accumulates that many limb products in fp32 on the bf16 matrix
+    cores (``gemm_x3_kernel`` in csrc/kernels/gemm_f32.hip; 8 drops only the 2^-32 term).  Set it before the first
+    step: wgrad workspace sizes depend on it.  No effect on the CPU reference path."""
+    if nv.kernels_available():
+        nv.kernels().dtf_gemm_set_split_products(int(n))
+
+
+def gemm_split_products() -> int:
+    return int(nv.kernels().dtf_gemm_get_split_products()) if nv.kernels_available() else 0
+
+
 def _bf16_round(t: torch.Tensor) -> torch.Tensor:
     """fp32 values rounded to bf16 (nearest even), as the bf16-operand kernels round their operands."""
     return t.to(torch.bfloat16).to(torch.float32)
