@@ -1,0 +1,268 @@
+// First-layer convolution fused with its 2x2 max pooling (NHWC, stride 1, few input channels: KH*KW*Cin < 32).
+//
+// A network's first convolution (e.g. 5x5x1 -> 32 on 28x28 images) has a tiny K and a huge, short-lived output: the
+// unfused chain writes a patch matrix, the full-resolution activation, the pooled activation, and on the way back the
+// full-resolution gradient - hundreds of MB per step for a few MFLOP per pixel.  Here one wave owns 8 pooled pixels
+// (= 32 convolution pixels) x 32 output channels as ONE 32x32 MFMA tile:
+//
+//   forward   rows = conv pixels ordered so that the 4 members of a pooling window are rows 4q .. 4q+3, which the
+//             32x32 C/D layout puts into 4 consecutive registers of one lane: bias, ReLU, max and argmax are
+//             register-only, and only the pooled tensor and a 2-bit argmax (stored as a byte) leave the chip.
+//             A operands are gathered from the image one value per lane per k step (the image stays in L1/L2).
+//   wgrad     D[k][c] += patch[k][pixel] * dz[pixel][c], two pixels per v_mfma_f32_32x32x2_f32; dz is rebuilt in
+//             registers from the pooled gradient, the argmax and the ReLU mask (pooled output > 0), so the
+//             full-resolution gradient never exists.  Row K of the A operand is all ones: its result row is the
+//             bias gradient.  Every block writes one partial [K+1][F] slab; a small kernel adds the slabs.
+//
+// This is what TF runs as Conv2D + BiasAdd + Relu + MaxPool and their gradients for a first layer; the reference
+// network itself is dense only (/root/reference/example.py:149-154), the CNN is this framework's MNIST-shaped model.
+#include "common.h"
+
+namespace {
+
+struct ConvPoolGeom {
+    int B, H, W, C;         // input image
+    int KH, KW, pad_t, pad_l;
+    int PH, PW;             // pooled output (conv output is 2*PH x 2*PW)
+    int F;                  // output channels, multiple of 32
+    int K;                  // KH*KW*C, < 32
+    unsigned taps[32];      // tap k packed on the host: (dy + 64) | (dx + 64) << 8 | channel << 16 | valid << 31
+};
+
+// tap k of the patch -> (row offset, column offset, channel); k >= K is marked invalid
+struct Tap { int dy, dx, ci; bool ok; };
+__device__ __forceinline__ Tap unpack_tap(unsigned u) {
+    Tap t;
+    t.dy = (int)(u & 0xFF) - 64;
+    t.dx = (int)((u >> 8) & 0xFF) - 64;
+    t.ci = (int)((u >> 16) & 0x7FFF);
+    t.ok = (u >> 31) != 0;
+    return t;
+}
+__host__ __device__ __forceinline__ Tap tap_of(int k, const ConvPoolGeom& g) {
+    Tap t;
+    t.ok = k < g.K;
+    const int kk = t.ok ? k : 0;
+    t.ci = kk % g.C;
+    const int w = kk / g.C;
+    t.dx = w % g.KW - g.pad_l;
+    t.dy = w / g.KW - g.pad_t;
+    return t;
+}
+
+__global__ __launch_bounds__(256) void conv_pool_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, float* __restrict__ ypool,
+                                                            unsigned char* __restrict__ arg, const ConvPoolGeom g, int act,
+                                                            int n_pooled) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int c = blockIdx.y * 32 + r;                      // this lane's output channel (C/D column and B column)
+    const int ks = (g.K + 1) / 2;                           // MFMA steps of two taps
+    // B operand: lane (r, h) holds w[k = 2s + h][c]
+    float bw[16];
+    Tap tp[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        tp[s] = unpack_tap(h ? g.taps[2 * s + 1] : g.taps[2 * s]);
+        bw[s] = tp[s].ok ? w[(long long)(2 * s + h) * g.F + c] : 0.f;
+    }
+    const float bv = bias ? bias[c] : 0.f;
+    const int tiles = (n_pooled + 7) / 8;
+    for (int t = blockIdx.x * 4 + wave; t < tiles; t += gridDim.x * 4) {
+        // A operand: lane (r, h) holds patch[row r][k = 2s + h]; row r = pooled pixel r >> 2, window member r & 3
+        const int P = t * 8 + (r >> 2);
+        const bool pv = P < n_pooled;
+        const int Pc = pv ? P : 0;
+        const int px = Pc % g.PW, py = (Pc / g.PW) % g.PH, b = Pc / (g.PW * g.PH);
+        const int oy = 2 * py + ((r >> 1) & 1), ox = 2 * px + (r & 1);
+        const float* img = x + (long long)b * g.H * g.W * g.C;
+        float a[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int iy = oy + tp[s].dy, ix = ox + tp[s].dx;
+            const bool in = pv && tp[s].ok && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W && s < ks;
+            const float v = img[in ? (iy * g.W + ix) * g.C + tp[s].ci : 0];     // unconditional load, then select
+            a[s] = in ? v : 0.f;
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+            if (s < ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bw[s], acc, 0, 0, 0);
+        // rows of register i: (i & 3) + 8 * (i >> 2) + 4 * h  ->  pooled pixel 2 * (i >> 2) + h, member i & 3
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float m = acc[4 * q] + bv;
+            int am = 0;
+#pragma unroll
+            for (int e = 1; e < 4; ++e) {
+                const float v = acc[4 * q + e] + bv;
+                if (v > m) { m = v; am = e; }
+            }
+            if (act == ACT_RELU) m = fmaxf(m, 0.f);
+            const int Pq = t * 8 + 2 * q + h;
+            if (Pq < n_pooled) {
+                ypool[(long long)Pq * g.F + c] = m;
+                arg[(long long)Pq * g.F + c] = (unsigned char)am;
+            }
+        }
+    }
+}
+
+// one partial [K + 1][F] slab per block: rows 0 .. K-1 the filter gradient, row K the bias gradient
+__global__ __launch_bounds__(256) void conv_pool_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dpool,
+                                                              const float* __restrict__ ypool,
+                                                              const unsigned char* __restrict__ arg, float* __restrict__ slabs,
+                                                              long long slab_stride, const ConvPoolGeom g, int act, int n_pooled) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int c = blockIdx.y * 32 + r;                      // B column: output channel
+    const Tap tp = tap_of(r, g);                            // A row: tap r (row K is the ones row)
+    const bool ones = r == g.K;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const int tiles = (n_pooled + 7) / 8;
+    const int HW = g.PH * g.PW;
+    for (int t = blockIdx.x * 4 + wave; t < tiles; t += gridDim.x * 4) {
+        // MFMA step 2q + e covers the conv pixels of pooled pixel q, window row e; lane half h is the window column
+        float dzq[8];
+        int argq[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int P = t * 8 + q;
+            const bool pv = P < n_pooled;                    // loads are unconditional (clamped) so all 24 fly together
+            const long long o = (long long)(pv ? P : n_pooled - 1) * g.F + c;
+            float d = dpool[o];
+            const float yv = ypool[o];
+            int am = arg[o];
+            if (act == ACT_RELU && !(yv > 0.f)) d = 0.f;
+            if (!pv) { d = 0.f; am = -1; }
+            dzq[q] = d;
+            argq[q] = am;
+        }
+        // image position of the tile's first pooled pixel, then one step per pooled pixel (all wave-uniform)
+        int b = (t * 8) / HW;
+        int rem = t * 8 - b * HW;
+        int py = rem / g.PW, px = rem - py * g.PW;
+        float a[16];                                         // all gathers of the tile in flight before the first MFMA
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const bool pv = t * 8 + q < n_pooled;
+            const float* img = x + (long long)(pv ? b : 0) * g.H * g.W * g.C;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {                    // window row e: conv pixels (2py + e, 2px + h)
+                const int iy = 2 * py + e + tp.dy, ix = 2 * px + h + tp.dx;
+                const bool in = pv && tp.ok && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+                const float v = img[in ? (iy * g.W + ix) * g.C + tp.ci : 0];      // unconditional load, then select
+                a[2 * q + e] = ones ? 1.f : (in ? v : 0.f);
+            }
+            if (++px == g.PW) {
+                px = 0;
+                if (++py == g.PH) { py = 0; ++b; }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const float bz = (argq[s >> 1] == 2 * (s & 1) + h) ? dzq[s >> 1] : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bz, acc, 0, 0, 0);
+        }
+    }
+    // the block's four waves meet in LDS; one slab per block
+    __shared__ float red[4][16][64];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) red[wave][i][lane] = acc[i];
+    __syncthreads();
+    float* slab = slabs + (long long)blockIdx.x * slab_stride;
+    for (int idx = threadIdx.x; idx < 1024; idx += 256) {
+        const int i = idx >> 6, l = idx & 63;
+        const float v = (red[0][i][l] + red[1][i][l]) + (red[2][i][l] + red[3][i][l]);
+        const int k = (i & 3) + 8 * (i >> 2) + 4 * (l >> 5);
+        if (k <= g.K) slab[(long long)k * g.F + blockIdx.y * 32 + (l & 31)] = v;
+    }
+}
+
+// out[i] = sum over slabs; 1024 threads = 16 outputs x 64 slab groups
+__global__ __launch_bounds__(1024) void conv_pool_reduce_kernel(const float* __restrict__ slabs, long long slab_stride, int n_slabs,
+                                                                float* __restrict__ dW, int n_main, float* __restrict__ db,
+                                                                int n_total) {
+    __shared__ float part[64][16];
+    const int e = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + e;
+    float s = 0.f;
+    if (i < n_total)
+        for (int k = grp; k < n_slabs; k += 64) s += slabs[(long long)k * slab_stride + i];
+    part[grp][e] = s;
+    __syncthreads();
+    if (grp == 0 && i < n_total) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 64; ++k) t += part[k][e];
+        if (i < n_main) dW[i] = t;
+        else if (db) db[i - n_main] = t;
+    }
+}
+
+void fill_taps(ConvPoolGeom& g) {
+    for (int k = 0; k < 32; ++k) {
+        const Tap t = tap_of(k, g);
+        g.taps[k] = (unsigned)(t.dy + 64) | ((unsigned)(t.dx + 64) << 8) | ((unsigned)t.ci << 16) | (t.ok ? 0x80000000u : 0u);
+    }
+}
+
+bool geom_ok(const ConvPoolGeom& g) {
+    return g.B > 0 && g.H > 0 && g.W > 0 && g.C > 0 && g.K == g.KH * g.KW * g.C && g.K < 32 && g.F > 0 && g.F % 32 == 0 &&
+           g.KH <= 32 && g.KW <= 32 && g.PH > 0 && g.PW > 0 && (long long)g.B * g.PH * g.PW < (1ll << 31) - 8 &&
+           (long long)g.B * g.H * g.W * g.C < (1ll << 31);
+}
+
+constexpr int WGRAD_BLOCKS = 1024;    // partial slabs; 4 waves per SIMD keep the gathers of several tiles in flight
+
+}  // namespace
+
+// 1 when the fused first-layer kernels take this shape
+DTF_API int dtf_conv_pool_supported(int C, int KH, int KW, int F) {
+    return (C > 0 && KH > 0 && KW > 0 && KH * KW * C < 32 && F > 0 && F % 32 == 0) ? 1 : 0;
+}
+
+// floats of scratch dtf_conv_pool_wgrad needs
+DTF_API long long dtf_conv_pool_workspace_floats(int C, int KH, int KW, int F) {
+    const long long stride = (((long long)(KH * KW * C + 1) * F + 3) / 4) * 4;
+    return stride * WGRAD_BLOCKS;
+}
+
+// ypool[B, PH, PW, F] = maxpool2x2(act(conv(x[B, H, W, C], w[KH*KW*C, F]) + bias)); arg = window member (dy*2+dx) of the max
+DTF_API int dtf_conv_pool_fwd(const float* x, const float* w, const float* bias, float* ypool, unsigned char* arg, int B, int H,
+                              int W, int C, int KH, int KW, int pad_t, int pad_l, int PH, int PW, int F, int act,
+                              hipStream_t stream) {
+    ConvPoolGeom g = {B, H, W, C, KH, KW, pad_t, pad_l, PH, PW, F, KH * KW * C, {}};
+    if (!geom_ok(g)) return -3;
+    fill_taps(g);
+    const int n_pooled = B * PH * PW;
+    const int tiles = (n_pooled + 7) / 8;
+    int blocks = (tiles + 3) / 4;
+    if (blocks > 2048) blocks = 2048;          // a wave amortises its filter registers over several tiles
+    hipLaunchKernelGGL(conv_pool_fwd_kernel, dim3(blocks, F / 32), dim3(256), 0, stream, x, w, bias, ypool, arg, g, act, n_pooled);
+    DTF_CHECK_LAUNCH();
+    return 0;
+}
+
+// dW[KH*KW*C, F], db[F] (may be null) from the pooled gradient dpool[B, PH, PW, F]
+DTF_API int dtf_conv_pool_wgrad(const float* x, const float* dpool, const float* ypool, const unsigned char* arg, float* dW,
+                                float* db, int B, int H, int W, int C, int KH, int KW, int pad_t, int pad_l, int PH, int PW,
+                                int F, int act, float* workspace, hipStream_t stream) {
+    ConvPoolGeom g = {B, H, W, C, KH, KW, pad_t, pad_l, PH, PW, F, KH * KW * C, {}};
+    if (!geom_ok(g) || !workspace) return -3;
+    fill_taps(g);
+    const int n_pooled = B * PH * PW;
+    const long long stride = (((long long)(g.K + 1) * F + 3) / 4) * 4;
+    hipLaunchKernelGGL(conv_pool_wgrad_kernel, dim3(WGRAD_BLOCKS, F / 32), dim3(256), 0, stream, x, dpool, ypool, arg, workspace,
+                       stride, g, act, n_pooled);
+    DTF_CHECK_LAUNCH();
+    const int n_main = g.K * F, n_total = (g.K + 1) * F;
+    hipLaunchKernelGGL(conv_pool_reduce_kernel, dim3((n_total + 15) / 16), dim3(1024), 0, stream, workspace, stride,
+                       WGRAD_BLOCKS, dW, n_main, db, n_total);
+    DTF_CHECK_LAUNCH();
+    return 0;
+}

@@ -307,6 +307,8 @@ class Conv2D(Layer):
         self.kernel = None
         self.bias = None
         self.fuse_prev_relu = False      # producing layer's ReLU gradient folded into this layer's col2im
+        self.fused_pool = None           # the 2x2 MaxPooling2D that follows, when the pair may run as one kernel
+        self._fused_ran = False
         self._buf = _Buffers()
         self._ws = None
         self._x = self._y = self._cols = None
@@ -378,8 +380,21 @@ class Conv2D(Layer):
         x = x.contiguous()
         B = x.shape[0]
         OH, OW, Fo = self.output_shape
-        y = self._buf.get("y", (B * OH * OW, Fo), x.device)
         bias = self.bias.tensor if self.bias is not None else None
+        self._fused_ran = self._fusable_with_pool(x)
+        if self._fused_ran:
+            # first layer + 2x2 pooling in one kernel: only the pooled tensor and the arg-max leave the chip; the
+            # pooling layer passes that tensor (and, backwards, the pooled gradient) through untouched
+            pool = self.fused_pool
+            shape = (B, OH // 2, OW // 2, Fo)
+            ypool = pool._buf.get("y", shape, x.device)
+            arg = pool._arg_buffer(shape, x.device)
+            kh, kw = self.kernel_size
+            F.conv_pool_forward(x, self.kernel.tensor.view(-1, Fo), bias, self.act, kh, kw, self.padding, ypool, arg)
+            self._x, self._cols, self._y = x, None, ypool
+            pool._x, pool._arg = None, arg
+            return ypool
+        y = self._buf.get("y", (B * OH * OW, Fo), x.device)
         self._used_implicit = self._implicit(x)
         if self._used_implicit:
             g = self._geometry(x)
@@ -392,7 +407,25 @@ class Conv2D(Layer):
         self._x, self._cols, self._y = x, cols, y
         return y.view(B, OH, OW, Fo)
 
+    def _fusable_with_pool(self, x) -> bool:
+        return (self.fused_pool is not None and x.is_cuda and not self.need_input_grad and self.act in (ACT_NONE, ACT_RELU)
+                and F.conv_pool_supported(x.shape, *self.kernel_size, self.filters, self.strides, self.padding,
+                                          self.fused_pool.pool_size))
+
+    def _backward_fused_pool(self, dpool):
+        x, ypool = self._x, self._y
+        kh, kw = self.kernel_size
+        Fo = self.filters
+        need = F.conv_pool_workspace_floats(x.shape[3], kh, kw, Fo)
+        if self._ws is None or self._ws[1].numel() < need:
+            self._ws = (0, torch.empty(need, dtype=torch.float32, device=x.device))
+        F.conv_pool_wgrad(x, dpool.contiguous(), ypool, self.fused_pool._arg, self.kernel.grad.view(-1, Fo),
+                          self.bias.grad if self.bias is not None else None, self.act, kh, kw, self.padding, self._ws[1])
+        return None
+
     def backward(self, dy):
+        if self._fused_ran:
+            return self._backward_fused_pool(dy)
         x, cols, y = self._x, self._cols, self._y
         M, Fo = y.shape
         kh, kw = self.kernel_size
@@ -454,6 +487,7 @@ class MaxPooling2D(Layer):
         if str(padding).lower() != "valid":
             raise NotImplementedError("MaxPooling2D supports padding='valid'")
         self.fold_relu_grad = False      # the pooled tensor is a ReLU output whose gradient this layer applies
+        self.fused_into = None           # the Conv2D in front, when the pair may run as one kernel
         self._buf = _Buffers()
         self._x = self._arg = None
 
@@ -466,21 +500,29 @@ class MaxPooling2D(Layer):
             raise ValueError("pool %s does not fit input %s" % (self.pool_size, input_shape))
         return (OH, OW, C)
 
+    def _arg_buffer(self, shape, device):
+        key = ("arg", tuple(shape), str(device))
+        arg = self._buf._b.get(key)
+        if arg is None:
+            arg = torch.empty(tuple(shape), dtype=torch.uint8, device=device)
+            self._buf._b[key] = arg
+        return arg
+
     def forward(self, x, training):
+        if self.fused_into is not None and self.fused_into._fused_ran:
+            return x                     # already pooled by the convolution's kernel
         x = x.contiguous()
         B = x.shape[0]
         shape = (B,) + tuple(self.output_shape)
         y = self._buf.get("y", shape, x.device)
-        key = ("arg", shape, str(x.device))
-        arg = self._buf._b.get(key)
-        if arg is None:
-            arg = torch.empty(shape, dtype=torch.uint8, device=x.device)
-            self._buf._b[key] = arg
+        arg = self._arg_buffer(shape, x.device)
         F.maxpool_forward(x, self.pool_size, out=y, arg=arg)
         self._x, self._arg = x, arg
         return y
 
     def backward(self, dy):
+        if self.fused_into is not None and self.fused_into._fused_ran:
+            return dy                    # the convolution's wgrad kernel consumes the pooled gradient
         x = self._x
         dx = self._buf.get("dx", x.shape, x.device)
         return F.maxpool_backward(dy.contiguous(), self._arg, x.shape, self.pool_size,

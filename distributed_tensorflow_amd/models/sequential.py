@@ -138,6 +138,10 @@ class Sequential:
                 a.grad_is_dz = True
         if eff:
             eff[0].need_input_grad = False
+        # a first-layer convolution followed by 2x2 pooling may run as one kernel (decided per call: GPU, shape)
+        if len(eff) > 1 and isinstance(eff[0], Conv2D) and isinstance(eff[1], MaxPooling2D) and eff[1].pool_size == (2, 2):
+            eff[0].fused_pool = eff[1]
+            eff[1].fused_into = eff[0]
         self._effective = eff
 
     # ------------------------------------------------------------------ compile

@@ -78,6 +78,10 @@ def kernels():
         "dtf_im2col": [c_p, c_p] + [c_i] * 12 + [c_p],
         "dtf_col2im": [c_p, c_p, c_p] + [c_i] * 12 + [c_p],
         "dtf_maxpool_fwd": [c_p, c_p, c_p] + [c_i] * 6 + [c_p],
+        "dtf_conv_pool_supported": [c_i] * 4,
+        "dtf_conv_pool_workspace_floats": [c_i] * 4,
+        "dtf_conv_pool_fwd": [c_p] * 5 + [c_i] * 12 + [c_p],
+        "dtf_conv_pool_wgrad": [c_p] * 6 + [c_i] * 12 + [c_p, c_p],
         "dtf_maxpool_bwd": [c_p, c_p, c_p, c_p] + [c_i] * 6 + [c_p],
         "dtf_conv_pad": [c_p, c_p] + [c_i] * 8 + [c_p],
         "dtf_conv_rowtab": [c_p] + [c_i] * 6 + [c_p],

@@ -559,6 +559,50 @@ def maxpool_forward(x, pool=(2, 2), out=None, arg=None):
     return out, arg
 
 
+def conv_pool_supported(x_shape, KH, KW, filters, strides=(1, 1), padding="valid", pool=(2, 2)) -> bool:
+    """True when a convolution followed by 2x2 max pooling can run as the fused first-layer kernels
+    (csrc/kernels/conv_pool.hip): stride 1, KH*KW*Cin < 32, filters a multiple of 32, even conv output size."""
+    if not nv.kernels_available() or tuple(strides) != (1, 1) or tuple(pool) != (2, 2):
+        return False
+    _, H, W, C = x_shape
+    OH, OW = conv_geometry(H, W, KH, KW, strides, padding)[:2]
+    if OH <= 0 or OW <= 0 or OH % 2 or OW % 2:
+        return False
+    return bool(nv.kernels().dtf_conv_pool_supported(C, KH, KW, filters))
+
+
+def conv_pool_workspace_floats(C, KH, KW, filters) -> int:
+    k = nv.kernels()
+    k.dtf_conv_pool_workspace_floats.restype = nv.c_ll
+    return int(k.dtf_conv_pool_workspace_floats(C, KH, KW, filters))
+
+
+def conv_pool_forward(x, w2d, bias, act, KH, KW, padding, ypool, arg):
+    """``ypool = maxpool2x2(act(conv(x, w) + bias))`` and the window member of each max, in one kernel (GPU only)."""
+    B, H, W, C = x.shape
+    OH, OW, pt, pl, _, _ = conv_geometry(H, W, KH, KW, (1, 1), padding)
+    Fo = w2d.shape[1]
+    nv.require_f32_contig(x, w2d, bias, ypool)
+    assert tuple(ypool.shape) == (B, OH // 2, OW // 2, Fo) and arg.shape == ypool.shape and arg.dtype == torch.uint8
+    rc = nv.kernels().dtf_conv_pool_fwd(nv.ptr(x), nv.ptr(w2d), nv.ptr(bias), nv.ptr(ypool), nv.ptr(arg), B, H, W, C, KH, KW,
+                                        pt, pl, OH // 2, OW // 2, Fo, act, nv.stream_ptr())
+    nv.check(rc, "dtf_conv_pool_fwd")
+    return ypool, arg
+
+
+def conv_pool_wgrad(x, dpool, ypool, arg, dw2d, db, act, KH, KW, padding, workspace):
+    """Filter and bias gradients of the fused convolution + pooling from the POOLED gradient (GPU only)."""
+    B, H, W, C = x.shape
+    OH, OW, pt, pl, _, _ = conv_geometry(H, W, KH, KW, (1, 1), padding)
+    Fo = dw2d.shape[1]
+    nv.require_f32_contig(x, dpool, ypool, dw2d, db, workspace)
+    assert dpool.shape == ypool.shape == arg.shape and dw2d.shape[0] == KH * KW * C
+    assert workspace.numel() >= conv_pool_workspace_floats(C, KH, KW, Fo)
+    rc = nv.kernels().dtf_conv_pool_wgrad(nv.ptr(x), nv.ptr(dpool), nv.ptr(ypool), nv.ptr(arg), nv.ptr(dw2d), nv.ptr(db), B, H, W,
+                                          C, KH, KW, pt, pl, OH // 2, OW // 2, Fo, act, nv.ptr(workspace), nv.stream_ptr())
+    nv.check(rc, "dtf_conv_pool_wgrad")
+
+
 def maxpool_backward(dy, arg, x_shape, pool=(2, 2), x_relu=None, out=None):
     """Route ``dy`` to each window's arg-max position; ``x_relu`` (the pooled tensor, a ReLU output) folds the ReLU
     gradient in."""
