@@ -520,12 +520,16 @@ class Sequential:
         x_ep = torch.empty_like(xd) if (shuffle or use_graph) else xd
         y_ep = torch.empty_like(yd) if (shuffle or use_graph) else yd
         full_steps = n // batch_size
+        # the epoch permutations come from their own generator: a run is reproducible from (shuffle_seed, initial_epoch)
+        # whatever else has drawn from the process-wide generators
+        shuffle_gen = torch.Generator(device=self.device).manual_seed(int(shuffle_seed) * 1000003 + int(initial_epoch)) \
+            if shuffle else None
         for epoch in range(initial_epoch, epochs):
             if self.stop_training:
                 break
             cl.call("on_epoch_begin", epoch, None)
             if shuffle:
-                perm = torch.randperm(n, device=self.device)
+                perm = torch.randperm(n, device=self.device, generator=shuffle_gen)
                 torch.index_select(xd, 0, perm, out=x_ep)
                 torch.index_select(yd, 0, perm, out=y_ep)
             elif use_graph and x_ep is not xd:

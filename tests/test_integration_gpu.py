@@ -48,9 +48,10 @@ def test_reference_workload_converges(gpu_device, path):
     Validation accuracy (rounded bits, dropout off) must reach the plateau of the CPU proxy (0.93), through the
     one-launch step kernel and through hipGraph replay of the layer-by-layer step.
     The plateau depends on the draw (data, initialisation, dropout masks, shuffling): single runs land between
-    about 0.90 and 0.985, so the claim is checked on the mean of three seeds."""
+    about 0.90 and 0.985, so the claim is checked on the mean of five seeds (runs are reproducible: data, initialisation,
+    dropout and the epoch shuffles are all seeded)."""
     finals = []
-    for seed in range(3):
+    for seed in range(5):
         xt, yt, xv, yv = get_data(30000, seed=1 + seed, device=gpu_device)
         m = xor_mlp()
         m.compile(loss="mean_squared_error", optimizer="adam", metrics=["binary_rounded_accuracy"], device=gpu_device,
