@@ -143,3 +143,24 @@ def test_data_generators():
     x, y = mnist_like(256, seed=1)
     assert x.shape == (256, 784) and y.dtype == torch.int64 and 0 <= int(y.min()) and int(y.max()) <= 9
     assert len(torch.unique(y)) >= 5
+
+
+def test_matmul_dtype_switch_is_validated_and_harmless_on_cpu():
+    """compile(matmul_dtype=...) drives a process-wide switch of the GPU GEMM kernels; on the CPU reference path the
+    three settings compute the same fp32 numbers."""
+    from distributed_tensorflow_amd.ops import functional as F
+    x = torch.rand(64, 64)
+    y = (torch.rand(64, 32) > 0.5).float()
+    outs = []
+    try:
+        for mode in ("fp32", "fp32_split", "bf16"):
+            m = xor_mlp(dropout=0.0)
+            m.compile(loss="mean_squared_error", optimizer="adam", device="cpu", seed=1, matmul_dtype=mode)
+            m.fit(x, y, batch_size=32, epochs=2, shuffle=False, verbose=0)
+            outs.append(m.store.flat.clone())
+        torch.testing.assert_close(outs[0], outs[1], rtol=0, atol=0)
+        torch.testing.assert_close(outs[0], outs[2], rtol=0, atol=0)
+        with pytest.raises(ValueError):
+            xor_mlp().compile(matmul_dtype="fp16")
+    finally:
+        F.set_gemm_split_products(0)
