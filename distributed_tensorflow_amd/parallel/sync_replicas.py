@@ -160,14 +160,18 @@ class SyncReplicasStrategy:
         store = model.store
         c = self.comm
         if self.world_size > 1 or self.force:
+            # a blocking-style call (async_op=False) orders the collective against the compute stream without the
+            # event hops to and from RCCL's side stream that an async op plus wait() costs (12 us per step measured
+            # on the latency-bound model); the host does not block either way.  DTF_ALLREDUCE_SYNC_OP=0 restores async.
+            use_async = c.backend == "nccl" and os.environ.get("DTF_ALLREDUCE_SYNC_OP", "1") == "0"
             if c.world_size == 1:      # forced single-rank collective (GPU-box test of the RCCL call path)
                 import torch.distributed as dist
-                work = dist.all_reduce(store.flat_grad, group=c.group, async_op=True) if c.backend == "nccl" else None
+                work = dist.all_reduce(store.flat_grad, group=c.group, async_op=use_async) if c.backend == "nccl" else None
             elif getattr(self, "p2p", None) is not None:
                 self.p2p.all_reduce_sum(store.flat_grad)
                 work = None
             else:
-                work = c.all_reduce_sum(store.flat_grad, async_op=(c.backend == "nccl"))
+                work = c.all_reduce_sum(store.flat_grad, async_op=use_async)
             if work is not None and hasattr(work, "wait"):
                 work.wait()            # stream-level wait under RCCL: the host does not block
         model.optimizer.apply_and_finish(store, grad_scale=scale)
