@@ -85,6 +85,116 @@ class TensorBoard(Callback):
             self.writer = None
 
 
+def _improved(value: float, best: Optional[float], mode: str, min_delta: float = 0.0) -> bool:
+    if best is None:
+        return True
+    return value < best - min_delta if mode == "min" else value > best + min_delta
+
+
+def _mode_for(monitor: str, mode: str) -> str:
+    if mode in ("min", "max"):
+        return mode
+    return "max" if "acc" in monitor else "min"
+
+
+class ModelCheckpoint(Callback):
+    """Save the model after every ``period`` epochs as a TensorBundle checkpoint (``Sequential.save_weights``).
+    ``filepath`` may contain ``{epoch}`` (1-based, Keras convention) and metric names, e.g.
+    ``"ckpt/weights.{epoch:02d}-{val_loss:.3f}"``.  ``save_best_only`` keeps only improvements of ``monitor``."""
+
+    def __init__(self, filepath: str, monitor: str = "val_loss", save_best_only: bool = False, mode: str = "auto",
+                 period: int = 1, verbose: int = 0):
+        super().__init__()
+        self.filepath, self.monitor, self.save_best_only = filepath, monitor, save_best_only
+        self.mode = _mode_for(monitor, mode)
+        self.period, self.verbose = max(1, int(period)), verbose
+        self.best: Optional[float] = None
+        self.saved: List[str] = []
+        self._since = 0
+
+    def on_epoch_end(self, epoch, logs=None):
+        import os
+        logs = logs or {}
+        self._since += 1
+        if self._since < self.period:
+            return
+        self._since = 0
+        if self.save_best_only:
+            cur = logs.get(self.monitor)
+            if cur is None or not _improved(float(cur), self.best, self.mode):
+                return
+            self.best = float(cur)
+        path = self.filepath.format(epoch=epoch + 1, **logs)
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        self.saved.append(self.model.save_weights(path))
+        if self.verbose:
+            sys.stdout.write("Epoch %05d: saving model to %s\n" % (epoch + 1, path))
+
+
+class EarlyStopping(Callback):
+    """Stop ``fit`` when ``monitor`` has not improved by ``min_delta`` for ``patience`` epochs;
+    ``restore_best_weights`` puts the best epoch's variables back."""
+
+    def __init__(self, monitor: str = "val_loss", min_delta: float = 0.0, patience: int = 0, mode: str = "auto",
+                 restore_best_weights: bool = False, verbose: int = 0):
+        super().__init__()
+        self.monitor, self.min_delta, self.patience = monitor, abs(float(min_delta)), int(patience)
+        self.mode = _mode_for(monitor, mode)
+        self.restore_best_weights, self.verbose = restore_best_weights, verbose
+
+    def on_train_begin(self, logs=None):
+        self.best: Optional[float] = None
+        self.wait = 0
+        self.stopped_epoch: Optional[int] = None
+        self._best_flat = None
+
+    def on_epoch_end(self, epoch, logs=None):
+        cur = (logs or {}).get(self.monitor)
+        if cur is None:
+            return
+        if _improved(float(cur), self.best, self.mode, self.min_delta):
+            self.best, self.wait = float(cur), 0
+            if self.restore_best_weights:
+                self._best_flat = self.model.store.flat.clone()
+            return
+        self.wait += 1
+        if self.wait > self.patience or (self.patience == 0 and self.wait >= 1):
+            self.stopped_epoch = epoch
+            self.model.stop_training = True
+            if self.restore_best_weights and self._best_flat is not None:
+                self.model.store.flat.copy_(self._best_flat)
+            if self.verbose:
+                sys.stdout.write("Epoch %05d: early stopping\n" % (epoch + 1))
+
+
+class CSVLogger(Callback):
+    """One CSV row of the epoch's metrics per epoch."""
+
+    def __init__(self, filename: str, separator: str = ",", append: bool = False):
+        super().__init__()
+        self.filename, self.sep, self.append = filename, separator, append
+        self._f = None
+        self._keys: Optional[List[str]] = None
+
+    def on_train_begin(self, logs=None):
+        self._f = open(self.filename, "a" if self.append else "w")
+        self._keys = None
+
+    def on_epoch_end(self, epoch, logs=None):
+        logs = logs or {}
+        if self._keys is None:
+            self._keys = sorted(logs)
+            if not (self.append and self._f.tell() > 0):
+                self._f.write(self.sep.join(["epoch"] + self._keys) + "\n")
+        self._f.write(self.sep.join([str(epoch)] + ["%.8g" % float(logs.get(k, float("nan"))) for k in self._keys]) + "\n")
+        self._f.flush()
+
+    def on_train_end(self, logs=None):
+        if self._f is not None:
+            self._f.close()
+            self._f = None
+
+
 class LambdaCallback(Callback):
     def __init__(self, on_epoch_end=None, on_batch_end=None, on_train_begin=None, on_train_end=None):
         super().__init__()

@@ -616,6 +616,49 @@ class Sequential:
         finally:
             pipe.close()
 
+    # ------------------------------------------------------------------ weights
+    def get_weights(self):
+        """The variables as NumPy arrays, in creation order (Keras ``model.get_weights()``)."""
+        self._check_built()
+        return [v.tensor.detach().cpu().numpy().copy() for v in self.store.variables.values()]
+
+    def set_weights(self, weights):
+        self._check_built()
+        variables = list(self.store.variables.values())
+        if len(weights) != len(variables):
+            raise ValueError("set_weights got %d arrays for %d variables" % (len(weights), len(variables)))
+        for v, w in zip(variables, weights):
+            w = torch.as_tensor(w, dtype=torch.float32)
+            if tuple(w.shape) != tuple(v.tensor.shape):
+                raise ValueError("shape mismatch for %s: %s vs %s" % (v.name, tuple(w.shape), tuple(v.tensor.shape)))
+            v.tensor.copy_(w)
+
+    def save_weights(self, filepath: str, include_optimizer: bool = True) -> str:
+        """Write the variables (and, by default, ``global_step`` and the optimizer slots) as a TensorFlow-readable
+        TensorBundle checkpoint ``<filepath>.index`` / ``<filepath>.data-00000-of-00001``; returns the prefix."""
+        from ..saver import Saver
+        self._check_built()
+        opt = self.optimizer if (include_optimizer and getattr(self, "optimizer", None) is not None) else None
+        if opt is not None:
+            opt.create_slots(self.store)
+        return Saver(self.store, optimizer=opt, max_to_keep=0).save(filepath, write_state=False)
+
+    def load_weights(self, filepath: str, strict: bool = False) -> int:
+        """Restore what ``filepath`` holds (variables; step and optimizer slots when present); returns global_step.
+        ``strict=True`` requires every persistent tensor of this model to be in the checkpoint."""
+        from ..saver import Saver
+        self._check_built()
+        opt = getattr(self, "optimizer", None)
+        if opt is not None:
+            opt.create_slots(self.store)          # so that slots found in the checkpoint have somewhere to go
+        step = Saver(self.store, optimizer=opt).restore(filepath, strict=strict)
+        self._host_step = step
+        return step
+
+    def _check_built(self):
+        if not self.built:
+            raise RuntimeError("build() or compile() the model first")
+
     # ------------------------------------------------------------------ misc
     def summary(self) -> str:
         lines = ["Model: %s" % self.name, "%-28s %-20s %10s" % ("Layer (type)", "Output Shape", "Param #")]

@@ -1,0 +1,83 @@
+"""Keras conveniences around Sequential: get/set/save/load weights (TensorBundle files) and the ModelCheckpoint /
+EarlyStopping / CSVLogger callbacks.  The reference drives checkpoints through MonitoredTrainingSession
+(/root/reference/example.py:189-192) and uses only the TensorBoard callback (/root/reference/example2.py:197-200);
+these are the neighbouring Keras entry points a user of `model.fit` reaches for."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from distributed_tensorflow_amd import callbacks as cb
+from distributed_tensorflow_amd.data import get_data
+from distributed_tensorflow_amd.models import xor_mlp
+from distributed_tensorflow_amd.saver import BundleReader
+
+
+def _model(seed=0):
+    m = xor_mlp(dropout=0.0)
+    m.compile(loss="mean_squared_error", optimizer="adam", metrics=["binary_rounded_accuracy"], device="cpu", seed=seed)
+    return m
+
+
+def test_get_set_weights_roundtrip():
+    a, b = _model(1), _model(2)
+    wa = a.get_weights()
+    assert [w.shape for w in wa] == [(64, 128), (128,), (128, 128), (128,), (128, 32), (32,)]
+    assert not np.allclose(wa[0], b.get_weights()[0])
+    b.set_weights(wa)
+    torch.testing.assert_close(a.store.flat, b.store.flat)
+    with pytest.raises(ValueError):
+        b.set_weights(wa[:-1])
+    with pytest.raises(ValueError):
+        b.set_weights([w.T for w in wa])
+
+
+def test_save_and_load_weights_keep_variables_step_and_adam_state(tmp_path):
+    xt, yt, xv, yv = get_data(600, val_set_size=100, seed=3)
+    a = _model(1)
+    a.fit(xt, yt, batch_size=50, epochs=2, verbose=0)
+    prefix = a.save_weights(str(tmp_path / "w" / "model"))
+    assert os.path.exists(prefix + ".index") and os.path.exists(prefix + ".data-00000-of-00001")
+    with BundleReader(prefix) as r:
+        names = set(r.get_variable_to_shape_map())
+    assert {"dense_1/kernel", "dense_3/bias", "global_step", "dense_1/kernel/Adam", "dense_1/kernel/Adam_1",
+            "beta1_power"} <= names
+    b = _model(9)
+    step = b.load_weights(prefix, strict=True)
+    assert step == a.global_step == 2 * (xt.shape[0] // 50)
+    torch.testing.assert_close(a.store.flat, b.store.flat)
+    torch.testing.assert_close(a.store.slot("m"), b.store.slot("m"))
+    # training continues identically from the restored state
+    a.fit(xt, yt, batch_size=50, epochs=1, shuffle=False, verbose=0)
+    b.fit(xt, yt, batch_size=50, epochs=1, shuffle=False, verbose=0)
+    torch.testing.assert_close(a.store.flat, b.store.flat)
+    # weights only: a fresh optimizer state is fine for a non-strict load
+    p2 = a.save_weights(str(tmp_path / "weights_only"), include_optimizer=False)
+    c = _model(5)
+    c.load_weights(p2)
+    torch.testing.assert_close(a.store.flat, c.store.flat)
+    with pytest.raises(KeyError):
+        _model(6).load_weights(p2, strict=True)
+
+
+def test_model_checkpoint_early_stopping_and_csv_logger(tmp_path):
+    xt, yt, xv, yv = get_data(1000, val_set_size=200, seed=4)
+    m = _model(2)
+    ck = cb.ModelCheckpoint(str(tmp_path / "ck" / "w.{epoch:02d}"), monitor="val_loss", save_best_only=True)
+    csv = cb.CSVLogger(str(tmp_path / "log.csv"))
+    h = m.fit(xt, yt, batch_size=50, epochs=4, validation_data=(xv, yv), callbacks=[ck, csv], verbose=0)
+    assert ck.saved and all(os.path.exists(p + ".index") for p in ck.saved)
+    best_epoch = int(np.argmin(h.history["val_loss"])) + 1
+    assert ck.saved[-1].endswith("w.%02d" % best_epoch)
+    rows = open(tmp_path / "log.csv").read().strip().splitlines()
+    assert rows[0].split(",")[0] == "epoch" and "val_loss" in rows[0] and len(rows) == 5
+
+    # a monitor that cannot improve (min_delta larger than any change) stops after `patience` more epochs
+    m2 = _model(3)
+    es = cb.EarlyStopping(monitor="val_loss", min_delta=10.0, patience=1, restore_best_weights=True)
+    snap = {}
+    grab = cb.LambdaCallback(on_epoch_end=lambda e, logs: snap.setdefault(e, m2.store.flat.clone()))
+    h2 = m2.fit(xt, yt, batch_size=50, epochs=10, validation_data=(xv, yv), callbacks=[grab, es], verbose=0)
+    assert len(h2.history["loss"]) == 3 and es.stopped_epoch == 2        # best = epoch 0, waited through 1 and 2
+    torch.testing.assert_close(m2.store.flat, snap[0])                   # best epoch's variables are back
