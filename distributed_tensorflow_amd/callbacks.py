@@ -167,6 +167,62 @@ class EarlyStopping(Callback):
                 sys.stdout.write("Epoch %05d: early stopping\n" % (epoch + 1))
 
 
+class LearningRateScheduler(Callback):
+    """``schedule(epoch, lr) -> lr`` (or ``schedule(epoch)``) evaluated at the start of every epoch."""
+
+    def __init__(self, schedule, verbose: int = 0):
+        super().__init__()
+        self.schedule, self.verbose = schedule, verbose
+
+    def on_epoch_begin(self, epoch, logs=None):
+        lr = self.model.optimizer.lr
+        try:
+            new = self.schedule(epoch, lr)
+        except TypeError:
+            new = self.schedule(epoch)
+        self.model.set_learning_rate(float(new))
+        if self.verbose:
+            sys.stdout.write("Epoch %05d: learning rate %.6g\n" % (epoch + 1, float(new)))
+
+    def on_epoch_end(self, epoch, logs=None):
+        if logs is not None:
+            logs["lr"] = self.model.optimizer.lr
+
+
+class ReduceLROnPlateau(Callback):
+    """Multiply the learning rate by ``factor`` when ``monitor`` has not improved for ``patience`` epochs."""
+
+    def __init__(self, monitor: str = "val_loss", factor: float = 0.1, patience: int = 10, min_delta: float = 1e-4,
+                 min_lr: float = 0.0, mode: str = "auto", verbose: int = 0):
+        super().__init__()
+        if factor >= 1.0:
+            raise ValueError("ReduceLROnPlateau needs factor < 1")
+        self.monitor, self.factor, self.patience = monitor, float(factor), int(patience)
+        self.min_delta, self.min_lr, self.verbose = abs(float(min_delta)), float(min_lr), verbose
+        self.mode = _mode_for(monitor, mode)
+
+    def on_train_begin(self, logs=None):
+        self.best: Optional[float] = None
+        self.wait = 0
+
+    def on_epoch_end(self, epoch, logs=None):
+        cur = (logs or {}).get(self.monitor)
+        if cur is None:
+            return
+        if _improved(float(cur), self.best, self.mode, self.min_delta):
+            self.best, self.wait = float(cur), 0
+            return
+        self.wait += 1
+        if self.wait >= self.patience:
+            old = self.model.optimizer.lr
+            new = max(old * self.factor, self.min_lr)
+            if new < old:
+                self.model.set_learning_rate(new)
+                if self.verbose:
+                    sys.stdout.write("Epoch %05d: reducing learning rate to %.6g\n" % (epoch + 1, new))
+            self.wait = 0
+
+
 class CSVLogger(Callback):
     """One CSV row of the epoch's metrics per epoch."""
 

@@ -509,7 +509,7 @@ class Sequential:
         params = {"epochs": epochs, "batch_size": batch_size, "steps": steps, "samples": n,
                   "metrics": ["loss"] + (["acc"] if self.metrics else [])}
         history = cb.History()
-        cbs = [history] + ([cb.ProgbarLogger()] if verbose else []) + list(callbacks or [])
+        cbs = list(callbacks or []) + ([cb.ProgbarLogger()] if verbose else []) + [history]   # History last, as in Keras: it sees what the others add to logs
         cl = cb.CallbackList(cbs, self, params)
         self.stop_training = False
         cl.call("on_train_begin", None)
@@ -591,7 +591,7 @@ class Sequential:
             params = {"epochs": epochs, "batch_size": batch_size, "steps": steps, "samples": n,
                       "metrics": ["loss"] + (["acc"] if self.metrics else [])}
             history = cb.History()
-            cbs = [history] + ([cb.ProgbarLogger()] if verbose else []) + list(callbacks or [])
+            cbs = list(callbacks or []) + ([cb.ProgbarLogger()] if verbose else []) + [history]   # History last, as in Keras: it sees what the others add to logs
             cl = cb.CallbackList(cbs, self, params)
             self.stop_training = False
             cl.call("on_train_begin", None)
@@ -615,6 +615,15 @@ class Sequential:
             return history
         finally:
             pipe.close()
+
+    # ------------------------------------------------------------------ learning rate
+    def set_learning_rate(self, lr: float):
+        """Change the optimizer's learning rate.  Captured hipGraphs hold the old value as a kernel argument, so they
+        are dropped and re-captured on their next use."""
+        self._check_compiled()
+        if float(lr) != self.optimizer.lr:
+            self.optimizer.lr = float(lr)
+            self._graphs.clear()
 
     # ------------------------------------------------------------------ weights
     def get_weights(self):

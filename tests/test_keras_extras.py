@@ -81,3 +81,24 @@ def test_model_checkpoint_early_stopping_and_csv_logger(tmp_path):
     h2 = m2.fit(xt, yt, batch_size=50, epochs=10, validation_data=(xv, yv), callbacks=[grab, es], verbose=0)
     assert len(h2.history["loss"]) == 3 and es.stopped_epoch == 2        # best = epoch 0, waited through 1 and 2
     torch.testing.assert_close(m2.store.flat, snap[0])                   # best epoch's variables are back
+
+
+def test_learning_rate_callbacks(tmp_path):
+    xt, yt, xv, yv = get_data(500, val_set_size=100, seed=5)
+    # a schedule equals training the epochs by hand with the same rates
+    a, b = _model(4), _model(4)
+    rates = [1e-3, 5e-4, 2.5e-4]
+    h = a.fit(xt, yt, batch_size=50, epochs=3, shuffle=False, verbose=0,
+              callbacks=[cb.LearningRateScheduler(lambda epoch, lr: rates[epoch])])
+    assert h.history["lr"] == rates
+    for e, lr in enumerate(rates):
+        b.set_learning_rate(lr)
+        b.fit(xt, yt, batch_size=50, epochs=e + 1, initial_epoch=e, shuffle=False, verbose=0)
+    torch.testing.assert_close(a.store.flat, b.store.flat)
+
+    m = _model(6)
+    rl = cb.ReduceLROnPlateau(monitor="val_loss", factor=0.5, patience=1, min_delta=10.0, min_lr=2e-4)
+    m.fit(xt, yt, batch_size=50, epochs=5, validation_data=(xv, yv), callbacks=[rl], verbose=0)
+    assert m.optimizer.lr == pytest.approx(2e-4)           # halved after epochs 1, 2 and 3, then held at the floor
+    with pytest.raises(ValueError):
+        cb.ReduceLROnPlateau(factor=1.5)
