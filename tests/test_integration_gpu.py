@@ -163,3 +163,21 @@ def test_graph_style_example_on_gpu(tmp_path):
     assert out.returncode == 0, out.stderr[-3000:]
     assert "Running single-machine training" in out.stdout and "Training complete!" in out.stdout
     assert "Validation Accuracy:" in out.stdout
+
+
+def test_learning_rate_change_recaptures_the_graph(gpu_device):
+    """A captured hipGraph holds the learning rate as a kernel argument: after a scheduler changes it, replayed steps
+    must use the new value (same result as eager launches)."""
+    from distributed_tensorflow_amd import callbacks as cb
+    from distributed_tensorflow_amd.models import mnist_mlp
+    from distributed_tensorflow_amd.data import mnist_like
+    x, y = mnist_like(2048, seed=5, device=gpu_device)
+    flats = []
+    for spg in (4, 0):
+        m = mnist_mlp(dropout=0.0)
+        m.compile(loss="sparse_categorical_crossentropy", optimizer="adam", metrics=["accuracy"], device=gpu_device, seed=2)
+        m.fit(x, y, batch_size=256, epochs=3, shuffle=False, verbose=0, steps_per_graph=spg, fused=False,
+              callbacks=[cb.LearningRateScheduler(lambda epoch, lr: 1e-3 * (0.3 ** epoch))])
+        assert m.optimizer.lr == pytest.approx(1e-3 * 0.09)
+        flats.append(m.store.flat.clone())
+    torch.testing.assert_close(flats[0], flats[1], rtol=1e-4, atol=1e-6)
