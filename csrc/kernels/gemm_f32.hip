@@ -137,6 +137,16 @@ struct TileLoader {
     __device__ __forceinline__ void load(int k0, int kbeg, int k_left, int tid) {
         const unsigned koff = KC ? (unsigned)k0 * 4u : (unsigned)(k0 - kbeg) * (unsigned)ld * 4u;
         const bool full = k_left >= BK;
+        if (full) {
+            // whole tile: the uniform tile offset rides in the instruction's scalar offset, the per-thread offset
+            // (already out of range for rows / columns outside the operand) is used as it is - no vector arithmetic
+#pragma unroll
+            for (int s = 0; s < NV; ++s) {
+                const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff[s], (int)koff, 0);
+                v[s] = __builtin_bit_cast(f32x4, raw);
+            }
+            return;
+        }
 #pragma unroll
         for (int s = 0; s < NV; ++s) {
             const int id = tid + 256 * s;
