@@ -127,6 +127,11 @@ class Dense(Layer):
         self._x = self._y = None
         self._keep_used = 1.0
 
+    def get_config(self):
+        return {"class": "Dense", "name": self.name, "units": self.units,
+                "activation": "softmax" if self.softmax else self.activation, "use_bias": self.use_bias,
+                "kernel_initializer": self.kernel_initializer, "bias_initializer": self.bias_initializer}
+
     def compute_output_shape(self, input_shape):
         if len(input_shape) != 1:
             raise ValueError("Dense expects flat inputs, got per-example shape %s (add Flatten())" % (input_shape,))
@@ -215,6 +220,9 @@ class Dropout(Layer):
         self._buf = _Buffers()
         self._active = False
 
+    def get_config(self):
+        return {"class": "Dropout", "name": self.name, "rate": self.rate, "seed": self.seed}
+
     def forward(self, x, training):
         self._active = training and self.rate > 0.0 and not self.fused_into_previous
         if not self._active:
@@ -236,8 +244,12 @@ class Activation(Layer):
         super().__init__(name=name)
         if activation not in ("relu", "sigmoid"):
             raise ValueError("Activation layer supports relu / sigmoid")
+        self.activation = activation
         self.act = ACT_CODES[activation]
         self._buf = _Buffers()
+
+    def get_config(self):
+        return {"class": "Activation", "name": self.name, "activation": self.activation}
 
     def forward(self, x, training):
         y = self._buf.get("y", x.shape, x.device)
@@ -471,7 +483,8 @@ class Conv2D(Layer):
 
     def get_config(self):
         return {"class": "Conv2D", "name": self.name, "filters": self.filters, "kernel_size": self.kernel_size,
-                "strides": self.strides, "padding": self.padding, "activation": self.activation}
+                "strides": self.strides, "padding": self.padding, "activation": self.activation, "use_bias": self.use_bias,
+                "kernel_initializer": self.kernel_initializer, "bias_initializer": self.bias_initializer}
 
 
 class MaxPooling2D(Layer):
@@ -530,3 +543,17 @@ class MaxPooling2D(Layer):
 
     def get_config(self):
         return {"class": "MaxPooling2D", "name": self.name, "pool_size": self.pool_size}
+
+
+def layer_from_config(cfg: dict) -> Layer:
+    """Rebuild a layer from its ``get_config()`` dictionary (``class`` names the layer type)."""
+    classes = {c.__name__: c for c in (Dense, Dropout, Activation, Flatten, Conv2D, MaxPooling2D)}
+    kw = {k: v for k, v in cfg.items() if k != "class"}
+    try:
+        cls = classes[cfg["class"]]
+    except KeyError:
+        raise ValueError("unknown layer class %r" % (cfg.get("class"),))
+    for k in ("kernel_size", "strides", "pool_size", "input_shape"):
+        if k in kw and kw[k] is not None:
+            kw[k] = tuple(kw[k])
+    return cls(**kw)

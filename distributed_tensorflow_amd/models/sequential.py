@@ -680,4 +680,48 @@ class Sequential:
         return "\n".join(lines)
 
     def get_config(self):
-        return {"name": self.name, "layers": [l.get_config() for l in self.layers]}
+        """Architecture as plain data; the first layer carries the per-example ``input_shape`` once it is known."""
+        layers = [dict(l.get_config()) for l in self.layers]
+        if layers and self.layers[0].input_shape is not None:
+            layers[0]["input_shape"] = list(self.layers[0].input_shape)
+        return {"name": self.name, "layers": layers}
+
+    @classmethod
+    def from_config(cls, config: dict) -> "Sequential":
+        from ..layers import layer_from_config
+        m = cls(name=config.get("name", "sequential"))
+        for lc in config["layers"]:
+            m.add(layer_from_config(lc))
+        return m
+
+    def to_json(self) -> str:
+        import json
+        return json.dumps(self.get_config(), indent=1)
+
+    def save(self, filepath: str, include_optimizer: bool = True) -> str:
+        """Keras ``model.save``: ``<filepath>.json`` (architecture) next to a TensorBundle checkpoint with the
+        variables and, by default, the step and optimizer slots.  ``load_model(filepath)`` rebuilds it."""
+        import os
+        os.makedirs(os.path.dirname(os.path.abspath(filepath)), exist_ok=True)
+        with open(filepath + ".json", "w") as f:
+            f.write(self.to_json())
+        return self.save_weights(filepath, include_optimizer=include_optimizer)
+
+
+def model_from_json(text: str) -> Sequential:
+    import json
+    return Sequential.from_config(json.loads(text))
+
+
+def load_model(filepath: str, compile_args: Optional[dict] = None) -> Sequential:
+    """Rebuild a model written by ``Sequential.save``.  With ``compile_args`` (keyword arguments of ``compile``) the
+    model is compiled first, so optimizer slots and ``global_step`` in the file are restored too; without them the
+    model is only built (on ``compile_args``-less calls the default device) and its variables restored."""
+    with open(filepath + ".json") as f:
+        m = model_from_json(f.read())
+    if compile_args is not None:
+        m.compile(**compile_args)
+    else:
+        m.build()
+    m.load_weights(filepath)
+    return m

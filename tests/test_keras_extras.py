@@ -102,3 +102,25 @@ def test_learning_rate_callbacks(tmp_path):
     assert m.optimizer.lr == pytest.approx(2e-4)           # halved after epochs 1, 2 and 3, then held at the floor
     with pytest.raises(ValueError):
         cb.ReduceLROnPlateau(factor=1.5)
+
+
+def test_model_save_and_load_model_rebuild_architecture_and_state(tmp_path):
+    from distributed_tensorflow_amd.models import load_model, mnist_cnn, model_from_json
+    xt, yt, _, _ = get_data(300, val_set_size=50, seed=6)
+    a = _model(7)
+    a.fit(xt, yt, batch_size=50, epochs=1, verbose=0)
+    path = a.save(str(tmp_path / "saved" / "xor"))
+    assert os.path.exists(path + ".json") and os.path.exists(path + ".index")
+    b = load_model(path, compile_args=dict(loss="mean_squared_error", optimizer="adam", device="cpu"))
+    assert [type(l).__name__ for l in b.layers] == [type(l).__name__ for l in a.layers]
+    assert b.global_step == a.global_step
+    torch.testing.assert_close(a.store.flat, b.store.flat)
+    torch.testing.assert_close(a.predict(xt[:20]), b.predict(xt[:20]))
+    c = load_model(path)                              # not compiled: variables only
+    torch.testing.assert_close(a.store.flat[:a.store.num_params], c.store.flat[:a.store.num_params])
+    # every layer type survives the JSON round trip
+    cnn = mnist_cnn()
+    twin = model_from_json(cnn.to_json())
+    assert twin.get_config()["layers"] == cnn.get_config()["layers"]
+    twin.build(device="cpu")
+    assert twin.store.num_params == 5 * 5 * 32 + 32 + 5 * 5 * 32 * 64 + 64 + 3136 * 512 + 512 + 5120 + 10
