@@ -35,6 +35,14 @@ constexpr int LDK = BK + 4;  // row stride (floats) of a k-contiguous LDS tile
 constexpr int LDKB = BK + 8; // row stride (bf16 elements, 80 bytes) of a bf16 LDS tile: 16-byte fragment reads of 8
                              // consecutive rows fall into distinct bank groups
 
+// Element offset of (row R, k) in a bf16 LDS image [rows][LDKB].  The four 16-byte chunks of a row are XOR-swizzled
+// with bits 4-5 of the row: fragment reads (16 consecutive rows, one chunk) stay conflict-free, and the transposing
+// loader's 8-byte stores, whose 32 lanes hit rows 4 apart (bank stride 16 of 64), spread over all 16 chunk slots
+// (2-way instead of 8-way conflicts).
+__device__ __forceinline__ int bf16_lds_off(int R, int k) {
+    return R * LDKB + ((((k >> 3) ^ (R >> 4)) & 3) << 3) + (k & 7);
+}
+
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -207,14 +215,14 @@ struct TileLoader {
                 bf16x4 y;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) y[j] = (__bf16)x[j];
-                *reinterpret_cast<bf16x4*>(lds + r * LDKB + c) = y;
+                *reinterpret_cast<bf16x4*>(lds + bf16_lds_off(r, c)) = y;
             } else {
                 const int c = id / (ROWS / 4), r = (id % (ROWS / 4)) * 4;      // c = k index, r = first of 4 rows
                 const int lim = mn_left - r;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const __bf16 y = (__bf16)((j == 0 || j < lim) ? x[j] : 0.f);
-                    lds[(r + j) * LDKB + c] = __builtin_bit_cast(unsigned short, y);
+                    lds[bf16_lds_off(r + j, c)] = __builtin_bit_cast(unsigned short, y);
                 }
             }
         }
@@ -233,7 +241,7 @@ struct TileLoader {
                 split3(v[s][j], a, b, c);
                 hi[j] = a; mid[j] = b; lo[j] = c;
             }
-            unsigned short* d = lds + (id >> 3) * LDKB + (id & 7) * 4;
+            unsigned short* d = lds + bf16_lds_off(id >> 3, (id & 7) * 4);
             *reinterpret_cast<bf16x4*>(d) = hi;
             *reinterpret_cast<bf16x4*>(d + plane) = mid;
             *reinterpret_cast<bf16x4*>(d + 2 * plane) = lo;
@@ -281,7 +289,7 @@ struct TransposeLoader {
             bf16x4 y;
 #pragma unroll
             for (int s = 0; s < NV; ++s) y[s] = (__bf16)((j == 0 || j < lim) ? v[s][j] : 0.f);
-            *reinterpret_cast<bf16x4*>(lds + (r + j) * LDKB + c0) = y;
+            *reinterpret_cast<bf16x4*>(lds + bf16_lds_off(r + j, c0)) = y;
         }
     }
     // limb planes as in TileLoader::store_split; the M/N extent is a multiple of 4, so a loaded vector is all inside
@@ -297,7 +305,7 @@ struct TransposeLoader {
                 split3(v[s][j], a, b, c);
                 hi[s] = a; mid[s] = b; lo[s] = c;
             }
-            unsigned short* d = lds + (r + j) * LDKB + c0;
+            unsigned short* d = lds + bf16_lds_off(r + j, c0);
             *reinterpret_cast<bf16x4*>(d) = hi;
             *reinterpret_cast<bf16x4*>(d + plane) = mid;
             *reinterpret_cast<bf16x4*>(d + 2 * plane) = lo;
@@ -694,10 +702,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs p) {
         for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                a[ks][i] = *reinterpret_cast<const bf16x8*>(As + ((wm * TM + i) * 32 + li) * LDKB + ks * 16 + 8 * h);
+                a[ks][i] = *reinterpret_cast<const bf16x8*>(As + bf16_lds_off((wm * TM + i) * 32 + li, ks * 16 + 8 * h));
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                b[ks][j] = *reinterpret_cast<const bf16x8*>(Bs + ((wn * TN + j) * 32 + li) * LDKB + ks * 16 + 8 * h);
+                b[ks][j] = *reinterpret_cast<const bf16x8*>(Bs + bf16_lds_off((wn * TN + j) * 32 + li, ks * 16 + 8 * h));
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -801,10 +809,10 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const GemmArgs p) {
             for (int l = 0; l < 3; ++l) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
-                    a[l][i] = *reinterpret_cast<const bf16x8*>(smem + l * TILE + ((wm * TM + i) * 32 + li) * LDKB + ks * 16 + 8 * h);
+                    a[l][i] = *reinterpret_cast<const bf16x8*>(smem + l * TILE + bf16_lds_off((wm * TM + i) * 32 + li, ks * 16 + 8 * h));
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    b[l][j] = *reinterpret_cast<const bf16x8*>(smem + (3 + l) * TILE + ((wn * TN + j) * 32 + li) * LDKB + ks * 16 + 8 * h);
+                    b[l][j] = *reinterpret_cast<const bf16x8*>(smem + (3 + l) * TILE + bf16_lds_off((wn * TN + j) * 32 + li, ks * 16 + 8 * h));
             }
 #pragma unroll
             for (int q = NPROD - 1; q >= 0; --q)
