@@ -315,6 +315,21 @@ __global__ __launch_bounds__(256) void pad_nhwc_kernel(const float* __restrict__
     }
 }
 
+// the same for channel counts that are not multiples of 4 (a 1- or 3-channel input image): one thread per element
+__global__ __launch_bounds__(256) void pad_nhwc_scalar_kernel(const float* __restrict__ src, float* __restrict__ dst, int B,
+                                                              int H, int W, int C, int pt, int pl, int Hp, int Wp,
+                                                              long long total) {
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int c = (int)(idx % C);
+        const long long pix = idx / C;
+        const int wp = (int)(pix % Wp);
+        const int hp = (int)((pix / Wp) % Hp);
+        const int b = (int)(pix / ((long long)Wp * Hp));
+        const int h = hp - pt, w = wp - pl;
+        dst[idx] = (h >= 0 && h < H && w >= 0 && w < W) ? src[(((long long)b * H + h) * W + w) * C + c] : 0.f;
+    }
+}
+
 // rowtab[(b*OH + oh)*OW + ow] = ((b*Hp + oh)*Wp + ow) * C : origin of the patch of output pixel (b, oh, ow)
 __global__ __launch_bounds__(256) void conv_rowtab_kernel(int* __restrict__ rowtab, int B, int OH, int OW, int Hp, int Wp,
                                                           int C, long long total) {
@@ -342,8 +357,14 @@ __global__ __launch_bounds__(256) void conv_flip_kernel(const float* __restrict_
 
 DTF_API int dtf_conv_pad(const float* src, float* dst, int B, int H, int W, int C, int pt, int pl, int Hp, int Wp,
                          hipStream_t stream) {
-    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 || pt < 0 || pl < 0 || Hp < H + pt || Wp < W + pl) return -3;
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || pt < 0 || pl < 0 || Hp < H + pt || Wp < W + pl) return -3;
     if ((long long)B * Hp * Wp * C >= (1ll << 31)) return -8;        // offsets are 32-bit element indices
+    if (C % 4) {
+        const long long n = (long long)B * Hp * Wp * C;
+        hipLaunchKernelGGL(pad_nhwc_scalar_kernel, dim3(grid_for(n)), dim3(256), 0, stream, src, dst, B, H, W, C, pt, pl, Hp, Wp, n);
+        DTF_CHECK_LAUNCH();
+        return 0;
+    }
     const long long total = (long long)B * Hp * Wp * (C / 4);
     hipLaunchKernelGGL(pad_nhwc_kernel, dim3(grid_for(total)), dim3(256), 0, stream, src, dst, B, H, W, C, pt, pl, Hp, Wp, total);
     DTF_CHECK_LAUNCH();

@@ -50,6 +50,9 @@ __host__ __device__ __forceinline__ Tap tap_of(int k, const ConvPoolGeom& g) {
     return t;
 }
 
+// CHECK = false: the caller guarantees every tap of every window lies inside the image (VALID convolution, e.g. of
+// an image that was zero-padded beforehand), so a tap costs one address add instead of bounds tests and selects.
+template <bool CHECK>
 __global__ __launch_bounds__(256) void conv_pool_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ bias, float* __restrict__ ypool,
                                                             unsigned char* __restrict__ arg, const ConvPoolGeom g, int act,
@@ -58,31 +61,44 @@ __global__ __launch_bounds__(256) void conv_pool_fwd_kernel(const float* __restr
     const int r = lane & 31, h = lane >> 5;
     const int c = blockIdx.y * 32 + r;                      // this lane's output channel (C/D column and B column)
     const int ks = (g.K + 1) / 2;                           // MFMA steps of two taps
-    // B operand: lane (r, h) holds w[k = 2s + h][c]
+    // B operand: lane (r, h) holds w[k = 2s + h][c]; tap of step s: offset inside the image relative to the pixel
     float bw[16];
     Tap tp[16];
+    int toff[16];
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
         tp[s] = unpack_tap(h ? g.taps[2 * s + 1] : g.taps[2 * s]);
+        toff[s] = tp[s].ok ? (tp[s].dy * g.W + tp[s].dx) * g.C + tp[s].ci : 0;
         bw[s] = tp[s].ok ? w[(long long)(2 * s + h) * g.F + c] : 0.f;
     }
     const float bv = bias ? bias[c] : 0.f;
     const int tiles = (n_pooled + 7) / 8;
+    const int HW = g.PH * g.PW;
     for (int t = blockIdx.x * 4 + wave; t < tiles; t += gridDim.x * 4) {
-        // A operand: lane (r, h) holds patch[row r][k = 2s + h]; row r = pooled pixel r >> 2, window member r & 3
-        const int P = t * 8 + (r >> 2);
-        const bool pv = P < n_pooled;
-        const int Pc = pv ? P : 0;
-        const int px = Pc % g.PW, py = (Pc / g.PW) % g.PH, b = Pc / (g.PW * g.PH);
+        // A operand: lane (r, h) holds patch[row r][k = 2s + h]; row r = pooled pixel r >> 2, window member r & 3.
+        // The tile's first pooled pixel is decoded once (wave-uniform), a lane steps at most 7 pixels on from it.
+        int b = (t * 8) / HW;
+        const int rem = t * 8 - b * HW;
+        int py = rem / g.PW, px = rem - py * g.PW + (r >> 2);
+        while (px >= g.PW) {
+            px -= g.PW;
+            if (++py == g.PH) { py = 0; ++b; }
+        }
+        const bool pv = t * 8 + (r >> 2) < n_pooled;
+        if (!pv) { b = 0; py = 0; px = 0; }
         const int oy = 2 * py + ((r >> 1) & 1), ox = 2 * px + (r & 1);
-        const float* img = x + (long long)b * g.H * g.W * g.C;
+        const float* pix = x + ((long long)b * g.H * g.W + oy * g.W + ox) * g.C;
         float a[16];
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-            const int iy = oy + tp[s].dy, ix = ox + tp[s].dx;
-            const bool in = pv && tp[s].ok && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W && s < ks;
-            const float v = img[in ? (iy * g.W + ix) * g.C + tp[s].ci : 0];     // unconditional load, then select
-            a[s] = in ? v : 0.f;
+            if (CHECK) {
+                const int iy = oy + tp[s].dy, ix = ox + tp[s].dx;
+                const bool in = pv && tp[s].ok && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W && s < ks;
+                const float v = pix[in ? toff[s] : -((oy * g.W + ox) * g.C)];     // unconditional load (image start if outside)
+                a[s] = in ? v : 0.f;
+            } else {
+                a[s] = pix[toff[s]];                        // taps past K multiply a zero filter row
+            }
         }
         f32x16 acc;
 #pragma unroll
@@ -111,6 +127,7 @@ __global__ __launch_bounds__(256) void conv_pool_fwd_kernel(const float* __restr
 }
 
 // one partial [K + 1][F] slab per block: rows 0 .. K-1 the filter gradient, row K the bias gradient
+template <bool CHECK>
 __global__ __launch_bounds__(256) void conv_pool_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dpool,
                                                               const float* __restrict__ ypool,
                                                               const unsigned char* __restrict__ arg, float* __restrict__ slabs,
@@ -154,7 +171,7 @@ __global__ __launch_bounds__(256) void conv_pool_wgrad_kernel(const float* __res
 #pragma unroll
             for (int e = 0; e < 2; ++e) {                    // window row e: conv pixels (2py + e, 2px + h)
                 const int iy = 2 * py + e + tp.dy, ix = 2 * px + h + tp.dx;
-                const bool in = pv && tp.ok && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+                const bool in = CHECK ? (pv && tp.ok && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) : (pv && tp.ok);
                 const float v = img[in ? (iy * g.W + ix) * g.C + tp.ci : 0];      // unconditional load, then select
                 a[2 * q + e] = ones ? 1.f : (in ? v : 0.f);
             }
@@ -211,6 +228,11 @@ void fill_taps(ConvPoolGeom& g) {
     }
 }
 
+// every tap of every pooling window inside the image?
+bool taps_inside(const ConvPoolGeom& g) {
+    return g.pad_t == 0 && g.pad_l == 0 && 2 * g.PH + g.KH - 1 <= g.H && 2 * g.PW + g.KW - 1 <= g.W;
+}
+
 bool geom_ok(const ConvPoolGeom& g) {
     return g.B > 0 && g.H > 0 && g.W > 0 && g.C > 0 && g.K == g.KH * g.KW * g.C && g.K < 32 && g.F > 0 && g.F % 32 == 0 &&
            g.KH <= 32 && g.KW <= 32 && g.PH > 0 && g.PW > 0 && (long long)g.B * g.PH * g.PW < (1ll << 31) - 8 &&
@@ -243,7 +265,10 @@ DTF_API int dtf_conv_pool_fwd(const float* x, const float* w, const float* bias,
     const int tiles = (n_pooled + 7) / 8;
     int blocks = (tiles + 3) / 4;
     if (blocks > 2048) blocks = 2048;          // a wave amortises its filter registers over several tiles
-    hipLaunchKernelGGL(conv_pool_fwd_kernel, dim3(blocks, F / 32), dim3(256), 0, stream, x, w, bias, ypool, arg, g, act, n_pooled);
+    if (taps_inside(g))
+        hipLaunchKernelGGL(conv_pool_fwd_kernel<false>, dim3(blocks, F / 32), dim3(256), 0, stream, x, w, bias, ypool, arg, g, act, n_pooled);
+    else
+        hipLaunchKernelGGL(conv_pool_fwd_kernel<true>, dim3(blocks, F / 32), dim3(256), 0, stream, x, w, bias, ypool, arg, g, act, n_pooled);
     DTF_CHECK_LAUNCH();
     return 0;
 }
@@ -257,8 +282,12 @@ DTF_API int dtf_conv_pool_wgrad(const float* x, const float* dpool, const float*
     fill_taps(g);
     const int n_pooled = B * PH * PW;
     const long long stride = (((long long)(g.K + 1) * F + 3) / 4) * 4;
-    hipLaunchKernelGGL(conv_pool_wgrad_kernel, dim3(WGRAD_BLOCKS, F / 32), dim3(256), 0, stream, x, dpool, ypool, arg, workspace,
-                       stride, g, act, n_pooled);
+    if (taps_inside(g))
+        hipLaunchKernelGGL(conv_pool_wgrad_kernel<false>, dim3(WGRAD_BLOCKS, F / 32), dim3(256), 0, stream, x, dpool, ypool, arg,
+                           workspace, stride, g, act, n_pooled);
+    else
+        hipLaunchKernelGGL(conv_pool_wgrad_kernel<true>, dim3(WGRAD_BLOCKS, F / 32), dim3(256), 0, stream, x, dpool, ypool, arg,
+                           workspace, stride, g, act, n_pooled);
     DTF_CHECK_LAUNCH();
     const int n_main = g.K * F, n_total = (g.K + 1) * F;
     hipLaunchKernelGGL(conv_pool_reduce_kernel, dim3((n_total + 15) / 16), dim3(1024), 0, stream, workspace, stride,

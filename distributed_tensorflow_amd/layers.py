@@ -402,8 +402,9 @@ class Conv2D(Layer):
             ypool = pool._buf.get("y", shape, x.device)
             arg = pool._arg_buffer(shape, x.device)
             kh, kw = self.kernel_size
-            F.conv_pool_forward(x, self.kernel.tensor.view(-1, Fo), bias, self.act, kh, kw, self.padding, ypool, arg)
-            self._x, self._cols, self._y = x, None, ypool
+            xin = self._fused_input(x)
+            F.conv_pool_forward(xin, self.kernel.tensor.view(-1, Fo), bias, self.act, kh, kw, "valid", ypool, arg)
+            self._x, self._cols, self._y = xin, None, ypool
             pool._x, pool._arg = None, arg
             return ypool
         y = self._buf.get("y", (B * OH * OW, Fo), x.device)
@@ -424,6 +425,17 @@ class Conv2D(Layer):
                 and F.conv_pool_supported(x.shape, *self.kernel_size, self.filters, self.strides, self.padding,
                                           self.fused_pool.pool_size))
 
+    def _fused_input(self, x):
+        """The fused kernels run a VALID convolution: 'same' padding is materialised once per step (a few MB for a
+        first layer), which frees every tap of both kernels from bounds tests."""
+        _, H, W, C = x.shape
+        kh, kw = self.kernel_size
+        _, _, pt, pl, pb, pr = F.conv_geometry(H, W, kh, kw, self.strides, self.padding)
+        if pt == pl == pb == pr == 0:
+            return x
+        xpad = self._buf.get("xpad_fused", (x.shape[0], H + pt + pb, W + pl + pr, C), x.device)
+        return F.conv_pad(x, pt, pl, H + pt + pb, W + pl + pr, out=xpad)
+
     def _backward_fused_pool(self, dpool):
         x, ypool = self._x, self._y
         kh, kw = self.kernel_size
@@ -432,7 +444,7 @@ class Conv2D(Layer):
         if self._ws is None or self._ws[1].numel() < need:
             self._ws = (0, torch.empty(need, dtype=torch.float32, device=x.device))
         F.conv_pool_wgrad(x, dpool.contiguous(), ypool, self.fused_pool._arg, self.kernel.grad.view(-1, Fo),
-                          self.bias.grad if self.bias is not None else None, self.act, kh, kw, self.padding, self._ws[1])
+                          self.bias.grad if self.bias is not None else None, self.act, kh, kw, "valid", self._ws[1])
         return None
 
     def backward(self, dy):
