@@ -26,7 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# CPU proxy of the reference workload measured for BASELINE.md (examples/s, 1 thread, PyTorch CPU)
+# CPU proxy of the reference workload (examples/s, 1 thread, PyTorch CPU): the denominator of "vs_baseline"
 BASELINE_EXAMPLES_PER_SEC = 37700.0
 
 
