@@ -25,6 +25,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# must be in place before the first GPU call of the process: RCCL's intra-node transport needs dmabuf IPC here
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 # CPU proxy of the reference workload (examples/s, 1 thread, PyTorch CPU): the denominator of "vs_baseline"
 BASELINE_EXAMPLES_PER_SEC = 37700.0
