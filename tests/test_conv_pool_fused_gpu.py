@@ -83,3 +83,39 @@ def test_model_step_with_the_fused_pair_matches_the_unfused_chain(gpu_device):
     for a, c in zip(*losses):
         assert abs(a - c) < 1e-4
     torch.testing.assert_close(grads[0], grads[1], rtol=1e-3, atol=2e-5)
+
+
+@pytest.mark.parametrize("C", [1, 3, 8])
+def test_conv_pad_any_channel_count(gpu_device, C):
+    """Zero padding of an NHWC image (the fused first layer pads a 'same' input once): float4 kernel for channel
+    counts divisible by 4, scalar kernel otherwise, against torch.nn.functional.pad."""
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn(3, 9, 7, C, generator=g).to(gpu_device)
+    out = F.conv_pad(x, 2, 1, 9 + 2 + 3, 7 + 1 + 2)
+    ref = torch.nn.functional.pad(x, (0, 0, 1, 2, 2, 3))
+    assert torch.equal(out, ref)
+
+
+def test_same_padded_three_channel_first_layer_through_the_layer_pair(gpu_device):
+    """Conv2D(3 -> 32, 3x3, same) + MaxPooling2D as layers: the fused pair (pad once, VALID kernels) against the
+    unfused chain, forward output and filter / bias gradients."""
+    from distributed_tensorflow_amd.models import Sequential
+    from distributed_tensorflow_amd.layers import Dense, Flatten
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(16, 12, 12, 3, generator=g).to(gpu_device)
+    y = torch.randint(0, 10, (16,), generator=g).to(gpu_device)
+    flats = []
+    for fused in (True, False):
+        m = Sequential()
+        m.add(Conv2D(32, (3, 3), padding="same", activation="relu", input_shape=(12, 12, 3)))
+        m.add(MaxPooling2D((2, 2)))
+        m.add(Flatten())
+        m.add(Dense(10, activation="softmax"))
+        m.compile(loss="sparse_categorical_crossentropy", optimizer="sgd", device=gpu_device, seed=4)
+        if not fused:
+            m._effective[0].fused_pool, m._effective[1].fused_into = None, None
+        for _ in range(3):
+            m.train_step(x, y)
+        assert m._effective[0]._fused_ran == fused
+        flats.append(m.store.flat.clone())
+    torch.testing.assert_close(flats[0], flats[1], rtol=1e-4, atol=1e-6)
