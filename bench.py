@@ -61,7 +61,7 @@ def parse_args():
     return ap.parse_args()
 
 
-DEFAULT_BATCH = {"mnist_mlp": 131072, "xor_mlp": 32768, "mnist_cnn": 4096, "wide_mlp": 8192}
+DEFAULT_BATCH = {"mnist_mlp": 262144, "xor_mlp": 32768, "mnist_cnn": 4096, "wide_mlp": 8192}
 
 
 def main():
