@@ -103,6 +103,12 @@ class Sequential:
         for layer in self.layers:
             shape = layer.build(shape, self.store)
         self.output_shape = shape
+        if seed is not None:
+            # dropout streams follow the model seed, not the process-wide count of layers created so far: a run is
+            # reproducible from compile(seed=...) whatever else the process has built before
+            for idx, layer in enumerate(self.layers):
+                if hasattr(layer, "seed"):
+                    layer.seed = (int(seed) * 1000003 + idx * 7919 + 12345) & 0x7FFFFFFF
         self._plan_fusion()
         self.device = torch.device(device) if device is not None else default_device()
         self.store.finalize(self.device, seed=seed, pad_multiple=pad_multiple)

