@@ -199,6 +199,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # diagnostic, outside the timed region: what one gradient exchange of the latency-bound path costs on this node
+    # (back-to-back all-reduces of the flat gradient buffer; every rank takes part)
+    exchange_us = None
+    if multi and args.mode == "sync" and getattr(strategy, "replicated", False) and dist.get_backend() == "nccl":
+        buf = torch.zeros_like(model.store.flat_grad)
+        for _ in range(5):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            dist.all_reduce(buf)
+        e1.record()
+        torch.cuda.synchronize()
+        exchange_us = e0.elapsed_time(e1) * 1000.0 / 20
+
     logs = model.read_stats()
     test_acc = None
     if args.eval > 0:
@@ -235,6 +251,7 @@ def main():
             "config": {"model": args.model, "global_batch": global_batch, "batch_per_gpu": B, "seq_len": None,
                        "parallelism": ("dp%d" if args.mode == "sync" else "async-ps%d") % world, "params": model.store.num_params,
                        "optimizer": "adam", "hip_graph": bool(use_graph), "fused_step_kernel": plan is not None, "allreduce": args.allreduce if multi else None,
+                       "allreduce_us": exchange_us,
                        "train_loss": logs.get("loss"), "train_acc": logs.get("acc"), "test_acc": test_acc,
                        **({"max_staleness": args.max_staleness, "staleness_histogram_rank0": staleness}
                           if staleness is not None else {})},
