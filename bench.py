@@ -1,11 +1,18 @@
 #!/usr/bin/env python
 """Headline benchmark: examples/sec of sync-replica data-parallel training of the
 MNIST-shaped MLP (784 -> 128 relu -> dropout .3 -> 128 relu -> dropout .3 -> 10 softmax,
-Adam, softmax cross-entropy) in fp32 on N MI355X GPUs of one node.
+Adam, softmax cross-entropy) in fp32 on N MI355X GPUs of one node, plus test accuracy.
 
     python bench.py --gpus 1 --steps 50 --warmup 10
+    python bench.py --gpus 8 --steps 50 --warmup 10          # starts 8 ranks itself, one per GPU, over RCCL
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
         --master-port 29500 bench.py --gpus 8 --steps 50 --warmup 10
+
+Launching.  Under torchrun (RANK / WORLD_SIZE in the environment) the process is one rank.  Started plainly with
+``--gpus N > 1`` it is a launcher: before anything touches a GPU it starts N rank processes of itself (one per GPU,
+the reference's "N worker processes", /root/reference/example.py:124-141), relays rank 0's JSON line and exits
+non-zero if any rank fails.  A machine with fewer than N GPUs is an error, never a silent smaller run: the printed
+``n_gpus`` always equals ``--gpus``.
 
 Every timed step is a complete training step on fresh device-resident synthetic data:
 forward, loss, backward, gradient exchange, Adam apply, global_step increment.  The
@@ -13,12 +20,19 @@ gradient exchange is one RCCL all-reduce of the flat gradient plus a replicated 
 the model is small (latency-bound; the default model is), and bucketed reduce-scatter ->
 sharded Adam -> all-gather overlapped with backward when it is large (--model wide_mlp).
 Weak scaling: the per-GPU batch is fixed.  Rank 0 prints ONE JSON line.
+
+Outside the timed region: the ``--warmup`` steps, then further untimed steps until the step time is steady (a box
+that has just started has not reached its sustained clocks), and - after the timed steps - ``--eval`` more training
+steps followed by the accuracy on a held-out synthetic test set (``config.test_acc``; the reference prints its
+validation accuracy, /root/reference/example.py:222-226).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,7 +46,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 BASELINE_EXAMPLES_PER_SEC = 37700.0
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -40,7 +54,9 @@ def parse_args():
     ap.add_argument("--model", default="mnist_mlp", choices=["mnist_mlp", "xor_mlp", "mnist_cnn", "wide_mlp"])
     ap.add_argument("--batch-per-gpu", type=int, default=0, help="0 = the model's default")
     ap.add_argument("--pool", type=int, default=4, help="distinct device-resident synthetic batches cycled through")
-    ap.add_argument("--graph", type=int, default=-1, help="replay the step from a hipGraph (-1 = auto: single GPU only)")
+    ap.add_argument("--graph", type=int, default=-1,
+                    help="replay the step from a hipGraph (-1 = auto: the whole step on one GPU; forward+backward of a "
+                         "small-batch replica whose launches would be host-bound; 0 = eager launches)")
     ap.add_argument("--fused", type=int, default=-1,
                     help="one-launch whole-step kernel for the small-batch reference MLP (-1 = when available, 0 = off)")
     ap.add_argument("--bucket-mb", type=float, default=64.0)
@@ -57,15 +73,101 @@ def parse_args():
                     help="fp32 (default): fp32 MFMA.  fp32_split: fp32 operands split exactly into three bf16 limbs, six "
                          "limb products accumulated in fp32 on the bf16 matrix cores (fp32-level accuracy).  bf16: opt-in "
                          "mixed precision for wide dense layers (bf16 operands, fp32 accumulation)")
-    ap.add_argument("--eval", type=int, default=0, help="also train for this many extra steps and report test accuracy")
-    return ap.parse_args()
+    ap.add_argument("--eval", type=int, default=-1,
+                    help="after the timed steps, train this many more steps (untimed) and report the accuracy on a held-out "
+                         "test set (-1 = auto: 100 steps, 5 for wide_mlp; 0 = skip)")
+    ap.add_argument("--steady", type=float, default=0.5,
+                    help="after --warmup, keep stepping (untimed) for at least this many seconds and until two consecutive "
+                         "10-step windows agree within 2 %% (0 = off)")
+    ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"],
+                    help="cpu: plumbing rehearsal of the launcher and the collectives over gloo (not a benchmark)")
+    return ap.parse_args(argv)
 
 
 DEFAULT_BATCH = {"mnist_mlp": 262144, "xor_mlp": 32768, "mnist_cnn": 4096, "wide_mlp": 8192}
 
 
-def main():
-    args = parse_args()
+# ----------------------------------------------------------------------------------------------- launcher
+def _under_launcher() -> bool:
+    """True when some launcher (torchrun, or this script's own) has already made this process one rank."""
+    return "RANK" in os.environ and "WORLD_SIZE" in os.environ
+
+
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args, argv) -> int:
+    """Start ``args.gpus`` rank processes of this script, wait for them, relay rank 0's JSON line.
+
+    Runs before this process has imported torch or made any GPU call; the children are fresh processes (never an exec
+    from a process that holds the GPU).  Returns the exit code: 0 only if every rank exited 0 and rank 0 printed a line.
+    """
+    n = args.gpus
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "DTF_BENCH_SELF_LAUNCHED": "1"})
+        env.setdefault("OMP_NUM_THREADS", "2")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    failed = None
+    try:
+        # rank 0's stdout is read to its end first: it ends when rank 0 exits (or is ended below through a failing peer)
+        import threading
+        lines = []
+
+        def pump():
+            for line in procs[0].stdout:
+                lines.append(line.rstrip("\n"))
+
+        t = threading.Thread(target=pump, daemon=True)
+        t.start()
+        pending = set(range(n))
+        while pending and failed is None:
+            for r in sorted(pending):
+                rc = procs[r].poll()
+                if rc is None:
+                    continue
+                pending.discard(r)
+                if rc != 0:
+                    failed = (r, rc)
+                    break
+            time.sleep(0.05)
+        t.join(timeout=5)
+    finally:
+        # end exactly the processes started above (a rank that failed leaves its peers blocked in a collective)
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        deadline = time.time() + 10
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+    if failed is not None:
+        sys.stderr.write("bench.py: rank %d of %d exited with status %d; no result\n" % (failed[0], n, failed[1]))
+        return failed[1] if failed[1] > 0 else 1
+    result = [l for l in lines if l.startswith("{")]
+    for l in lines:
+        if not l.startswith("{"):
+            sys.stderr.write(l + "\n")
+    if not result:
+        sys.stderr.write("bench.py: rank 0 printed no result line\n")
+        return 1
+    print(result[-1], flush=True)
+    return 0
+
+
+# ----------------------------------------------------------------------------------------------- one rank
+def run_rank(args) -> None:
     if args.allreduce == "p2p":
         os.environ["DTF_ALLREDUCE"] = "p2p"
     import torch
@@ -74,17 +176,35 @@ def main():
     from distributed_tensorflow_amd import data, models
     from distributed_tensorflow_amd.ops import _native
     from distributed_tensorflow_amd.parallel import Communicator, SyncReplicasStrategy, init_process_group
+    from distributed_tensorflow_amd.parallel.comm import pick_backend
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU")
-    dev = torch.device("cuda", local_rank % torch.cuda.device_count())
-    torch.cuda.set_device(dev)
-    _native.kernels()  # fail loudly if the HIP library is missing
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE); they must agree"
+                         % (args.gpus, world))
+    on_gpu = args.device == "cuda"
+    if on_gpu:
+        # counting devices does not initialise the GPU runtime, so this check is safe in every rank before rendezvous
+        ndev = torch.cuda.device_count()
+        if ndev < 1:
+            raise SystemExit("bench.py needs a GPU (none visible)")
+        backend = pick_backend(torch.device("cuda", 0))
+        if world > ndev and backend == "nccl":
+            raise SystemExit("bench.py: --gpus %d but this machine exposes %d GPU(s); RCCL needs one GPU per rank "
+                             "(DTF_COMM_BACKEND=gloo rehearses several ranks on one GPU)" % (world, ndev))
+        dev = torch.device("cuda", local_rank % ndev)
+        torch.cuda.set_device(dev)
+        _native.kernels()  # fail loudly if the HIP library is missing
+    else:
+        dev = torch.device("cpu")
+        backend = "gloo"
+        torch.set_num_threads(max(1, int(os.environ.get("OMP_NUM_THREADS", "2"))))
+
+    def sync_device():
+        if on_gpu:
+            torch.cuda.synchronize()
 
     strategy = None
     multi = world > 1 or bool(args.single_rank_collectives)
@@ -95,7 +215,7 @@ def main():
         from distributed_tensorflow_amd.parallel.async_ps import AsyncPSStrategy
         base = int(os.environ.get("MASTER_PORT", "29500")) + 16
         if world > 1:
-            init_process_group("nccl", device=dev)
+            init_process_group(backend, device=dev if on_gpu else None)
         hosts = ["127.0.0.1:%d" % (base + i) for i in range(world)]
         server = Server(ClusterSpec({"worker": hosts}), "worker", rank, config={"device": str(dev)})
         strategy = AsyncPSStrategy(server, max_staleness=args.max_staleness if args.max_staleness >= 0 else None)
@@ -104,13 +224,15 @@ def main():
         if world == 1:
             os.environ["DTF_FORCE_COLLECTIVES"] = "1"
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
-            init_process_group("nccl", rank=0, world_size=1, device=dev)
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+            init_process_group(backend, rank=0, world_size=1, device=dev if on_gpu else None)
         else:
-            init_process_group("nccl", device=dev)
+            init_process_group(backend, device=dev if on_gpu else None)
         strategy = SyncReplicasStrategy(Communicator(), bucket_bytes=int(args.bucket_mb * (1 << 20)))
+    data_plane = dist.get_backend() if dist.is_initialized() else None
 
     B = args.batch_per_gpu or DEFAULT_BATCH[args.model]
+    metrics = ["accuracy"]
     if args.model == "mnist_mlp":
         model = models.mnist_mlp()
         loss = "sparse_categorical_crossentropy"
@@ -118,6 +240,7 @@ def main():
     elif args.model == "xor_mlp":
         model = models.xor_mlp()
         loss = "mean_squared_error"
+        metrics = ["binary_rounded_accuracy"]       # the reference's accuracy (/root/reference/example.py:157-160)
         make = lambda n, seed: data.get_data(n, val_set_size=0, seed=seed, device=dev)[:2]
     elif args.model == "mnist_cnn":
         model = models.mnist_cnn()
@@ -129,7 +252,7 @@ def main():
         model = models.wide_mlp(width=args.width, depth=args.depth)
         loss = "sparse_categorical_crossentropy"
         make = lambda n, seed: data.mnist_like(n, seed=seed, device=dev)
-    model.compile(loss=loss, optimizer="adam", metrics=["accuracy"], strategy=strategy, device=dev, seed=0,
+    model.compile(loss=loss, optimizer="adam", metrics=metrics, strategy=strategy, device=dev, seed=0,
                   matmul_dtype=args.matmul)
 
     pool = max(1, args.pool)
@@ -142,16 +265,17 @@ def main():
     x_all, y_all = make(B * pool, 1000 + rank)
     batches = [(x_all[i * B:(i + 1) * B], y_all[i * B:(i + 1) * B]) for i in range(pool)]
 
-    use_graph = plan is None and args.mode == "sync" and ((args.graph == 1) or (args.graph == -1 and not multi))
     graphs = grad_graphs = None
-    if use_graph and not multi:
-        graphs = [model._graphed_steps(bx, by, B, 1) for bx, by in batches]
-    elif plan is None and args.graph == 1 and multi and getattr(strategy, "replicated", False):
-        # small per-GPU batches (host-bound eager launches): forward+loss+backward replays from a hipGraph, the
-        # gradient all-reduce and the replicated apply follow eagerly (RCCL stays outside the graph).  At the
-        # default batch the GPU is the bottleneck and eager launches measured 4 % faster, so this is opt-in.
-        grad_graphs = [model.graphed_gradients(bx, by) for bx, by in batches]
-        use_graph = True
+    replicated = bool(getattr(strategy, "replicated", False))
+    if on_gpu and plan is None and args.mode == "sync" and args.graph != 0:
+        if not multi:
+            graphs = [model._graphed_steps(bx, by, B, 1) for bx, by in batches]
+        elif replicated and (args.graph == 1 or B * model.store.num_params < (1 << 34)):
+            # a replica whose step is short enough to be bound by the host's eager launches: forward+loss+backward
+            # replays from a hipGraph, the gradient all-reduce and the replicated apply follow eagerly (RCCL stays
+            # outside the graph).  At large batches the GPU is the bottleneck and eager launches are as fast.
+            grad_graphs = [model.graphed_gradients(bx, by) for bx, by in batches]
+    use_graph = graphs is not None or grad_graphs is not None
 
     def run(first, count):
         """Training steps first .. first+count-1; step i consumes batch i % pool."""
@@ -174,35 +298,59 @@ def main():
                 bx, by = batches[i % pool]
                 model.train_step(bx, by)
 
-    def step(i):
-        run(i, 1)
-
     def barrier():
-        if dist.get_backend() == "nccl":
+        if data_plane == "nccl":
             dist.barrier(device_ids=[dev.index])
-        else:
-            dist.barrier()       # DTF_COMM_BACKEND=gloo: ranks time-sharing one GPU (rehearsal on a one-GPU box)
+        elif data_plane is not None:
+            dist.barrier()       # gloo: CPU ranks, or ranks time-sharing one GPU (rehearsal on a one-GPU box)
 
     def fence():
         if multi:
             barrier()
-        torch.cuda.synchronize()
+        sync_device()
 
+    def max_over_ranks(seconds: float) -> float:
+        if world > 1:
+            t = torch.tensor([seconds], dtype=torch.float64, device=dev if data_plane == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return seconds
+
+    # ---- untimed: the requested warm-up, then until the step time is steady (every rank takes the same decisions:
+    # they are made on the maximum over ranks)
     run(0, args.warmup)
     fence()
-    t0 = time.perf_counter()
-    run(args.warmup, args.steps)
+    done = args.warmup
+    steady_windows = 0
+    if args.steady > 0:
+        window, tol, cap = 10, 0.02, max(4.0, 8 * args.steady)
+        t_begin = time.perf_counter()
+        prev = None
+        while True:
+            t0 = time.perf_counter()
+            run(done, window)
+            fence()
+            dt = max_over_ranks(time.perf_counter() - t0)
+            done += window
+            steady_windows += 1
+            total = max_over_ranks(time.perf_counter() - t_begin)
+            agree = prev is not None and abs(dt - prev) <= tol * max(dt, prev)
+            if (agree and total >= args.steady) or total >= cap:
+                break
+            prev = dt
+
+    # ---- timed region: exactly --steps steps between two fences
     fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    t0 = time.perf_counter()
+    run(done, args.steps)
+    fence()
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+    done += args.steps
 
     # diagnostic, outside the timed region: what one gradient exchange of the latency-bound path costs on this node
-    # (back-to-back all-reduces of the flat gradient buffer; every rank takes part)
+    # (back-to-back all-reduces of the flat gradient buffer; every rank takes part: the condition is rank-independent)
     exchange_us = None
-    if multi and args.mode == "sync" and getattr(strategy, "replicated", False) and dist.get_backend() == "nccl":
+    if multi and args.mode == "sync" and replicated and data_plane == "nccl":
         buf = torch.zeros_like(model.store.flat_grad)
         for _ in range(5):
             dist.all_reduce(buf)
@@ -216,12 +364,18 @@ def main():
         exchange_us = e0.elapsed_time(e1) * 1000.0 / 20
 
     logs = model.read_stats()
+    # ---- test accuracy (untimed): a fixed budget of further training steps, then a held-out set every rank evaluates
+    # a slice of (the statistics are summed over ranks)
     test_acc = None
-    if args.eval > 0:
-        for i in range(args.eval):
-            step(i)
-        xt, yt = make(8192, 99)
-        test_acc = model.evaluate(xt, yt, batch_size=8192)[1]
+    n_eval = args.eval if args.eval >= 0 else (5 if args.model == "wide_mlp" else 100)
+    if n_eval > 0 and args.mode == "sync":
+        run(done, n_eval)
+        done += n_eval
+        n_test = 8192
+        xt, yt = make(n_test * world, 99)
+        res = model.evaluate(xt[rank * n_test:(rank + 1) * n_test], yt[rank * n_test:(rank + 1) * n_test],
+                             batch_size=n_test)
+        test_acc = res[1] if len(res) > 1 else None
 
     staleness = None
     if args.mode == "async":
@@ -231,6 +385,25 @@ def main():
         strategy.cp0.barrier("bench_done", world, timeout_s=300)
         if rank == 0:
             strategy.shutdown_owners()
+
+    # what the data plane itself reports: its size and the device every rank computes on
+    me = {"rank": rank, "device": str(dev), "pid": os.getpid()}
+    if on_gpu:
+        props = torch.cuda.get_device_properties(dev)
+        me["gpu"] = props.name
+        me["uuid"] = str(getattr(props, "uuid", ""))
+    ranks = [me]
+    group_size = 1
+    if dist.is_initialized():
+        group_size = dist.get_world_size()
+        if world > 1:
+            ranks = [None] * world
+            dist.all_gather_object(ranks, me)
+    if on_gpu and data_plane == "nccl" and world > 1:
+        distinct = {(r["device"], r.get("uuid")) for r in ranks}
+        if len(distinct) != world:
+            raise SystemExit("bench.py: %d ranks but only %d distinct GPUs: %r" % (world, len(distinct), ranks))
+
     global_batch = B * world
     value = global_batch * args.steps / elapsed
     if rank == 0:
@@ -238,7 +411,7 @@ def main():
             "metric": "examples/sec (whole node) %s MNIST-shape model" % ("sync-DP" if args.mode == "sync" else "async-PS"),
             "value": value,
             "unit": "examples/s",
-            "n_gpus": world,
+            "n_gpus": args.gpus,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1000.0 * elapsed / args.steps,
@@ -250,9 +423,15 @@ def main():
             "data": "synthetic (device-resident MNIST-shaped inputs, random-init weights)",
             "config": {"model": args.model, "global_batch": global_batch, "batch_per_gpu": B, "seq_len": None,
                        "parallelism": ("dp%d" if args.mode == "sync" else "async-ps%d") % world, "params": model.store.num_params,
-                       "optimizer": "adam", "hip_graph": bool(use_graph), "fused_step_kernel": plan is not None, "allreduce": args.allreduce if multi else None,
-                       "allreduce_us": exchange_us,
+                       "optimizer": "adam", "hip_graph": bool(use_graph), "fused_step_kernel": plan is not None,
+                       "allreduce": args.allreduce if multi else None, "allreduce_us": exchange_us,
                        "train_loss": logs.get("loss"), "train_acc": logs.get("acc"), "test_acc": test_acc,
+                       "eval_steps": n_eval if test_acc is not None else 0,
+                       "steady_warmup_steps": steady_windows * 10,
+                       "data_plane": {"nccl": "rccl"}.get(data_plane, data_plane), "rccl_ranks": group_size,
+                       "self_launched": os.environ.get("DTF_BENCH_SELF_LAUNCHED") == "1",
+                       "ranks": ranks,
+                       **({"device": "cpu (plumbing rehearsal, not a benchmark)"} if not on_gpu else {}),
                        **({"max_staleness": args.max_staleness, "staleness_histogram_rank0": staleness}
                           if staleness is not None else {})},
         }
@@ -261,6 +440,16 @@ def main():
         barrier()
     if dist.is_initialized():
         dist.destroy_process_group()
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and not _under_launcher():
+        sys.exit(self_launch(args, argv))
+    run_rank(args)
 
 
 if __name__ == "__main__":

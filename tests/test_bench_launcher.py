@@ -1,0 +1,67 @@
+"""bench.py started plainly (no torchrun): ``--gpus N > 1`` must start N ranks by itself, print ``n_gpus == N`` with N
+distinct ranks, and fail loudly - never run a smaller job silently - when the ranks cannot be had.  CPU rehearsal over
+gloo (``--device cpu``); the GPU twin lives in test_shared_gpu_ranks.py."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env(extra=None):
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "JOB_NAME", "TASK_INDEX", "PS_HOSTS",
+              "WORKER_HOSTS"):
+        env.pop(k, None)
+    env["OMP_NUM_THREADS"] = "1"
+    env.update(extra or {})
+    return env
+
+
+def _run(args, env=None, timeout=240):
+    return subprocess.run([sys.executable, BENCH] + args, env=_env(env), capture_output=True, text=True, timeout=timeout,
+                          cwd=ROOT)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_self_launch_runs_every_rank(world):
+    out = _run(["--gpus", str(world), "--device", "cpu", "--batch-per-gpu", "128", "--steps", "3", "--warmup", "1",
+                "--steady", "0.05", "--eval", "3"])
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                      # ONE JSON line, rank 0's
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == world and d["steps"] == 3 and d["warmup"] == 1
+    c = d["config"]
+    assert c["parallelism"] == "dp%d" % world and c["global_batch"] == 128 * world
+    assert c["rccl_ranks"] == world and c["self_launched"] is True
+    assert sorted(r["rank"] for r in c["ranks"]) == list(range(world))
+    assert len({r["pid"] for r in c["ranks"]}) == world          # really N processes
+    assert c["test_acc"] is not None and 0.0 <= c["test_acc"] <= 1.0
+    assert d["value"] > 0 and d["scaling"] == "weak"
+
+
+def test_missing_gpus_is_an_error_not_a_smaller_run():
+    """No GPU here: ``--gpus 2`` on the GPU path must exit non-zero and print no result line."""
+    out = _run(["--gpus", "2", "--steps", "2", "--warmup", "1"], env={"CUDA_VISIBLE_DEVICES": "", "HIP_VISIBLE_DEVICES": ""})
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert "GPU" in out.stderr
+
+
+def test_world_size_must_match_gpus():
+    out = _run(["--gpus", "2", "--device", "cpu"], env={"RANK": "0", "WORLD_SIZE": "1"})
+    assert out.returncode != 0 and "must agree" in (out.stderr + out.stdout)
+
+
+def test_async_mode_self_launched():
+    out = _run(["--gpus", "2", "--device", "cpu", "--mode", "async", "--batch-per-gpu", "64", "--steps", "4", "--warmup", "1",
+                "--steady", "0", "--max-staleness", "2"])
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "async-ps2"
+    assert sum(d["config"]["staleness_histogram_rank0"].values()) > 0

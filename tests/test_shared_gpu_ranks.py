@@ -89,3 +89,32 @@ def test_bench_two_ranks_share_the_gpu(allreduce):
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8192 and d["config"]["parallelism"] == "dp2"
     assert d["value"] > 0 and d["steps"] == 6 and d["config"]["allreduce"] == allreduce
     assert d["config"]["train_loss"] == d["config"]["train_loss"]      # finite, not NaN
+
+
+def test_bench_self_launch_two_ranks_share_the_gpu():
+    """Plain ``python bench.py --gpus 2`` (no torchrun): the script starts both ranks itself."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+           "--batch-per-gpu", "4096", "--steady", "0.1", "--eval", "10"]
+    out = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=WAIT, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    c = d["config"]
+    assert d["n_gpus"] == 2 and c["parallelism"] == "dp2" and c["rccl_ranks"] == 2 and c["self_launched"]
+    assert sorted(r["rank"] for r in c["ranks"]) == [0, 1] and len({r["pid"] for r in c["ranks"]}) == 2
+    assert c["test_acc"] is not None and c["test_acc"] > 0.5
+
+
+def test_bench_more_ranks_than_gpus_over_rccl_is_refused():
+    """RCCL needs one GPU per rank: ``--gpus 8`` on the one-GPU box exits non-zero with a message that says why, and
+    prints no result."""
+    env = _env()
+    env.pop("DTF_COMM_BACKEND")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1"],
+                         env=env, capture_output=True, text=True, timeout=WAIT, cwd=ROOT)
+    import torch
+    if torch.cuda.device_count() >= 8:
+        pytest.skip("this machine really has 8 GPUs")
+    assert out.returncode != 0
+    assert "exposes" in out.stderr and not [l for l in out.stdout.splitlines() if l.startswith("{")]
