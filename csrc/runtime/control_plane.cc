@@ -36,7 +36,16 @@ namespace {
 enum Op : uint8_t {
     OP_SET = 1, OP_GET = 2, OP_ADD = 3, OP_PUSH = 4, OP_POP = 5, OP_CLOCK_SET = 6, OP_CLOCK_WAIT = 7,
     OP_BARRIER = 8, OP_HEARTBEAT = 9, OP_DEAD = 10, OP_CLOCK_MIN = 11, OP_DELETE = 12, OP_QLEN = 13,
+    // folded operations: what used to be several round trips of one training step is one each
+    OP_TAKE_MANY = 14,        // block until every key exists, return all values, erase them
+    OP_PUSH_MANY = 15,        // append one value to each of several queues
+    OP_CLOCK_SET_WAIT = 16,   // publish my clock, then block until mine - min(group) <= bound
+    OP_WAIT_COUNTER = 17,     // block until a counter has reached a value
+    OP_ADD_SET = 18,          // add to a counter and set a key (the counter's new value is returned)
 };
+// A frame larger than this is a protocol error (or not one of our clients): the connection is dropped instead of
+// allocating what its 4-byte length asks for.
+constexpr uint32_t MAX_FRAME_BYTES = 64u << 20;
 enum Status : int32_t { ST_OK = 0, ST_TIMEOUT = 1, ST_ERROR = -1, ST_CLOSED = -2 };
 
 using Clock = std::chrono::steady_clock;
@@ -134,27 +143,49 @@ struct Server {
     int port = 0;
     std::thread accept_thread;
     std::mutex conn_mu;
-    std::vector<std::thread> conn_threads;
-    std::vector<int> conn_fds;
+    struct Conn { std::thread th; int fd = -1; bool done = false; };
+    std::map<uint64_t, Conn> conns;            // live (and finished, not yet joined) connections by id
+    uint64_t next_conn = 0;
 
-    void handle(int fd) {
+    void handle(uint64_t id, int fd) {
         int one = 1;
         setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
-        for (;;) {
-            uint32_t len;
-            uint8_t op;
-            if (!read_full(fd, &len, 4) || !read_full(fd, &op, 1)) break;
-            std::string body(len, '\0');
-            if (len && !read_full(fd, &body[0], len)) break;
-            Reader r(body);
-            Writer w;
-            int32_t status = ST_OK;
-            dispatch(op, r, w, status);
-            if (!r.ok) status = ST_ERROR;
-            uint32_t blen = static_cast<uint32_t>(w.b.size());
-            if (!write_full(fd, &blen, 4) || !write_full(fd, &status, 4) || (blen && !write_full(fd, w.b.data(), blen))) break;
+        try {
+            for (;;) {
+                uint32_t len;
+                uint8_t op;
+                if (!read_full(fd, &len, 4) || !read_full(fd, &op, 1)) break;
+                if (len > MAX_FRAME_BYTES) break;                   // not a frame of ours: drop the connection
+                std::string body(len, '\0');
+                if (len && !read_full(fd, &body[0], len)) break;
+                Reader r(body);
+                Writer w;
+                int32_t status = ST_OK;
+                dispatch(op, r, w, status);
+                if (!r.ok) status = ST_ERROR;
+                uint32_t blen = static_cast<uint32_t>(w.b.size());
+                if (!write_full(fd, &blen, 4) || !write_full(fd, &status, 4) || (blen && !write_full(fd, w.b.data(), blen))) break;
+            }
+        } catch (...) {
+            // a failed allocation or a malformed body ends this connection only, never the task
         }
+        // forget the descriptor BEFORE closing it: stop() must never shut down a number the process has reused
+        std::lock_guard<std::mutex> g(conn_mu);
+        auto it = conns.find(id);
+        if (it != conns.end()) { it->second.fd = -1; it->second.done = true; }
         ::close(fd);
+    }
+
+    // joins the threads of connections that have ended (called with conn_mu held, from the accept thread)
+    void reap_locked() {
+        for (auto it = conns.begin(); it != conns.end();) {
+            if (it->second.done) {
+                if (it->second.th.joinable()) it->second.th.join();
+                it = conns.erase(it);
+            } else {
+                ++it;
+            }
+        }
     }
 
     void dispatch(uint8_t op, Reader& r, Writer& w, int32_t& status) {
@@ -228,6 +259,57 @@ struct Server {
                 w.i64(clock_min(st.clocks[g]));
                 break;
             }
+            case OP_TAKE_MANY: {
+                uint32_t n = r.u32();
+                std::vector<std::string> keys;
+                for (uint32_t i = 0; i < n && r.ok; ++i) keys.push_back(r.str());
+                int64_t to = r.i64();
+                if (!r.ok) break;
+                auto all = [&] { for (auto& k : keys) if (!st.kv.count(k)) return false; return true; };
+                if (!wait_until(st, lk, to, all)) { status = ST_TIMEOUT; break; }
+                w.u32(n);
+                for (auto& k : keys) { w.str(st.kv[k]); st.kv.erase(k); }
+                break;
+            }
+            case OP_PUSH_MANY: {
+                uint32_t n = r.u32();
+                for (uint32_t i = 0; i < n && r.ok; ++i) {
+                    std::string q = r.str(), v = r.str();
+                    if (r.ok) st.queues[q].push_back(v);
+                }
+                st.cv.notify_all();
+                break;
+            }
+            case OP_CLOCK_SET_WAIT: {
+                std::string g = r.str();
+                int64_t member = r.i64(), value = r.i64(), bound = r.i64(), to = r.i64();
+                st.clocks[g][member] = value;
+                st.cv.notify_all();
+                auto ok = [&] { return bound < 0 || value - clock_min(st.clocks[g]) <= bound; };
+                if (!wait_until(st, lk, to, ok)) { status = ST_TIMEOUT; }
+                w.i64(clock_min(st.clocks[g]));
+                break;
+            }
+            case OP_WAIT_COUNTER: {
+                std::string k = r.str();
+                int64_t want = r.i64(), to = r.i64();
+                if (!wait_until(st, lk, to, [&] { return st.counters[k] >= want; })) { status = ST_TIMEOUT; }
+                w.i64(st.counters[k]);
+                break;
+            }
+            case OP_ADD_SET: {
+                std::string ck = r.str();
+                int64_t d = r.i64();
+                std::string k = r.str(), v = r.str();
+                int64_t nv = ck.empty() ? 0 : (st.counters[ck] += d);
+                // "%GS%" inside the value is replaced by the counter's new value (a reply that carries the step it made)
+                auto pos = v.find("%GS%");
+                if (pos != std::string::npos) v.replace(pos, 4, std::to_string(nv));
+                st.kv[k] = v;
+                w.i64(nv);
+                st.cv.notify_all();
+                break;
+            }
             case OP_BARRIER: {
                 std::string name = r.str();
                 int64_t n = r.i64(), to = r.i64();
@@ -297,8 +379,11 @@ struct Server {
                     break;
                 }
                 std::lock_guard<std::mutex> g(conn_mu);
-                conn_fds.push_back(fd);
-                conn_threads.emplace_back([this, fd] { handle(fd); });
+                reap_locked();
+                const uint64_t id = next_conn++;
+                Conn& c = conns[id];
+                c.fd = fd;
+                c.th = std::thread([this, id, fd] { handle(id, fd); });
             }
         });
         return true;
@@ -319,11 +404,15 @@ struct Server {
         std::vector<std::thread> threads;
         {
             std::lock_guard<std::mutex> g(conn_mu);
-            for (int fd : conn_fds) ::shutdown(fd, SHUT_RDWR);
-            threads.swap(conn_threads);
+            for (auto& kv : conns) {
+                if (kv.second.fd >= 0) ::shutdown(kv.second.fd, SHUT_RDWR);   // still open: owned by its thread
+                threads.push_back(std::move(kv.second.th));
+            }
         }
         for (auto& t : threads)
             if (t.joinable()) t.join();
+        std::lock_guard<std::mutex> g(conn_mu);
+        conns.clear();
     }
 };
 
@@ -485,4 +574,57 @@ DTF_EXPORT int dtf_cp_dead(void* c, int64_t max_age_ms, void* buf, int64_t cap, 
     int st = cl->call(OP_DEAD, w);
     if (st != ST_OK) return st;
     return copy_blob(cl->last, buf, cap, len);
+}
+
+// ---- folded operations (one round trip each)
+// keys: n NUL-terminated strings back to back.  Output: n blobs as u32 length + bytes, back to back, in key order.
+DTF_EXPORT int dtf_cp_take_many(void* c, const char* keys, int64_t n, void* buf, int64_t cap, int64_t* len, int64_t timeout_ms) {
+    Writer w; w.u32(static_cast<uint32_t>(n));
+    const char* p = keys;
+    for (int64_t i = 0; i < n; ++i) { std::string k(p); w.str(k); p += k.size() + 1; }
+    w.i64(timeout_ms);
+    auto* cl = static_cast<Client*>(c);
+    int st = cl->call(OP_TAKE_MANY, w);
+    if (st != ST_OK) return st;
+    if (cl->last.size() < 4) return ST_ERROR;
+    const int64_t payload = static_cast<int64_t>(cl->last.size()) - 4;
+    if (len) *len = payload;
+    if (payload > cap) return ST_ERROR;
+    std::memcpy(buf, cl->last.data() + 4, static_cast<size_t>(payload));
+    return ST_OK;
+}
+// items: n pairs (queue NUL-terminated, then u32 length + value bytes) back to back.
+DTF_EXPORT int dtf_cp_push_many(void* c, const void* items, int64_t items_len, int64_t n) {
+    Writer w; w.u32(static_cast<uint32_t>(n));
+    const char* p = static_cast<const char*>(items);
+    const char* end = p + items_len;
+    for (int64_t i = 0; i < n; ++i) {
+        std::string q(p); p += q.size() + 1;
+        uint32_t vl; if (p + 4 > end) return ST_ERROR; std::memcpy(&vl, p, 4); p += 4;
+        if (p + vl > end) return ST_ERROR;
+        w.str(q); w.blob(p, vl); p += vl;
+    }
+    return static_cast<Client*>(c)->call(OP_PUSH_MANY, w);
+}
+DTF_EXPORT int dtf_cp_clock_set_wait(void* c, const char* group, int64_t member, int64_t value, int64_t bound, int64_t timeout_ms,
+                                     int64_t* min_out) {
+    Writer w; w.str(group); w.i64(member); w.i64(value); w.i64(bound); w.i64(timeout_ms);
+    auto* cl = static_cast<Client*>(c);
+    int st = cl->call(OP_CLOCK_SET_WAIT, w);
+    if ((st == ST_OK || st == ST_TIMEOUT) && min_out) { Reader r(cl->last); *min_out = r.i64(); }
+    return st;
+}
+DTF_EXPORT int dtf_cp_wait_counter(void* c, const char* key, int64_t want, int64_t timeout_ms, int64_t* out) {
+    Writer w; w.str(key); w.i64(want); w.i64(timeout_ms);
+    auto* cl = static_cast<Client*>(c);
+    int st = cl->call(OP_WAIT_COUNTER, w);
+    if ((st == ST_OK || st == ST_TIMEOUT) && out) { Reader r(cl->last); *out = r.i64(); }
+    return st;
+}
+DTF_EXPORT int dtf_cp_add_set(void* c, const char* counter, int64_t delta, const char* key, const void* data, int64_t len, int64_t* out) {
+    Writer w; w.str(counter ? counter : ""); w.i64(delta); w.str(key); w.blob(data, static_cast<size_t>(len));
+    auto* cl = static_cast<Client*>(c);
+    int st = cl->call(OP_ADD_SET, w);
+    if (st == ST_OK && out) { Reader r(cl->last); *out = r.i64(); }
+    return st;
 }

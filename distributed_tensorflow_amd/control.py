@@ -41,6 +41,11 @@ def _rt():
     nv.declare(lib, "dtf_cp_barrier", [p, s, i64, i64])
     nv.declare(lib, "dtf_cp_heartbeat", [p, s])
     nv.declare(lib, "dtf_cp_dead", [p, i64, p, i64, pi64])
+    nv.declare(lib, "dtf_cp_take_many", [p, p, i64, p, i64, pi64, i64])
+    nv.declare(lib, "dtf_cp_push_many", [p, p, i64, i64])
+    nv.declare(lib, "dtf_cp_clock_set_wait", [p, s, i64, i64, i64, i64, pi64])
+    nv.declare(lib, "dtf_cp_wait_counter", [p, s, i64, i64, pi64])
+    nv.declare(lib, "dtf_cp_add_set", [p, s, i64, s, s, i64, pi64])
     _lib = lib
     return lib
 
@@ -80,8 +85,10 @@ class ControlClient:
             raise ControlPlaneError("cannot reach control plane at %s:%d" % (host, port))
         self.host, self.port = host, port
         self._buf = C.create_string_buffer(1 << 16)
+        self.calls = 0          # round trips made through this client (every method below is exactly one)
 
     def _check(self, st: int, what: str):
+        self.calls += 1
         if st == ST_OK:
             return
         if st == ST_TIMEOUT:
@@ -115,6 +122,7 @@ class ControlClient:
         return json.loads(self.get(key, timeout_s).decode())
 
     def delete(self, key: str):
+        self.calls += 1
         _rt().dtf_cp_delete(self._h, key.encode())
 
     # -- counters
@@ -157,6 +165,65 @@ class ControlClient:
         out = C.c_int64()
         st = _rt().dtf_cp_clock_wait(self._h, group.encode(), int(mine), int(bound), self._ms(timeout_s), C.byref(out))
         self._check(st, "clock_wait")
+        return out.value
+
+    # -- folded operations: one round trip each
+    def take_many(self, keys, timeout_s: Optional[float] = None) -> List[bytes]:
+        """Block until every key exists; return their values in order and erase them."""
+        import struct
+        keys = list(keys)
+        packed = b"".join(k.encode() + b"\0" for k in keys)
+        n = C.c_int64()
+        st = _rt().dtf_cp_take_many(self._h, packed, len(keys), self._buf, len(self._buf), C.byref(n), self._ms(timeout_s))
+        if st == ST_ERROR and n.value > len(self._buf):
+            raise ControlPlaneError("control-plane values of %d bytes exceed the client buffer" % n.value)
+        self._check(st, "take_many " + ",".join(keys[:3]))
+        raw, out, pos = self._buf.raw[:n.value], [], 0
+        for _ in keys:
+            (ln,) = struct.unpack_from("<I", raw, pos)
+            out.append(raw[pos + 4:pos + 4 + ln])
+            pos += 4 + ln
+        return out
+
+    def take_many_json(self, keys, timeout_s: Optional[float] = None):
+        return [json.loads(v.decode()) for v in self.take_many(keys, timeout_s)]
+
+    def take_json(self, key: str, timeout_s: Optional[float] = None):
+        return self.take_many_json([key], timeout_s)[0]
+
+    def push_many(self, items):
+        """``items``: (queue, bytes) pairs, appended in order."""
+        import struct
+        items = list(items)
+        packed = b"".join(q.encode() + b"\0" + struct.pack("<I", len(v)) + v for q, v in items)
+        self._check(_rt().dtf_cp_push_many(self._h, packed, len(packed), len(items)), "push_many")
+
+    def push_many_json(self, items):
+        self.push_many([(q, json.dumps(o).encode()) for q, o in items])
+
+    def clock_set_wait(self, group: str, member: int, value: int, bound: Optional[int],
+                       timeout_s: Optional[float] = None) -> int:
+        """Publish ``value`` as ``member``'s clock, then block until ``value - min(group clocks) <= bound``
+        (``bound=None``: publish only).  Returns the minimum clock."""
+        out = C.c_int64()
+        st = _rt().dtf_cp_clock_set_wait(self._h, group.encode(), int(member), int(value),
+                                         -1 if bound is None else int(bound), self._ms(timeout_s), C.byref(out))
+        self._check(st, "clock_set_wait")
+        return out.value
+
+    def wait_counter(self, key: str, want: int, timeout_s: Optional[float] = None) -> int:
+        """Block (on the server, no polling) until counter ``key`` >= ``want``; returns its value."""
+        out = C.c_int64()
+        self._check(_rt().dtf_cp_wait_counter(self._h, key.encode(), int(want), self._ms(timeout_s), C.byref(out)),
+                    "wait_counter " + key)
+        return out.value
+
+    def add_set(self, counter: Optional[str], delta: int, key: str, value: bytes) -> int:
+        """Add ``delta`` to ``counter`` (skipped when None) and set ``key`` to ``value``, where the text ``%GS%``
+        inside ``value`` becomes the counter's new value.  Returns that value."""
+        out = C.c_int64()
+        self._check(_rt().dtf_cp_add_set(self._h, (counter or "").encode(), int(delta), key.encode(), value, len(value),
+                                         C.byref(out)), "add_set " + key)
         return out.value
 
     # -- barrier / liveness

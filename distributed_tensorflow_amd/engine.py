@@ -54,9 +54,20 @@ class ModelEngine:
 
     # ---- global step
     def global_step_value(self) -> int:
-        gs = getattr(self.model.strategy, "global_step", None)
+        """The (cluster-wide) step counter without a device synchronisation: single-replica and synchronous-replica
+        training advance the counter exactly once per local step, so the model's host mirror is exact; asynchronous
+        workers take the value that came back with their last push (see ``AsyncPSStrategy.cached_global_step``)."""
+        st = self.model.strategy
+        cached = getattr(st, "cached_global_step", None)
+        if callable(cached):
+            return int(cached())
+        gs = getattr(st, "global_step", None)
         if callable(gs):
             return int(gs())
+        return int(self.model._host_step)
+
+    def device_global_step(self) -> int:
+        """The device-resident counter itself (one device->host read); what checkpoints record."""
         return int(self.model.store.global_step.item())
 
     # ---- checkpoints
@@ -94,6 +105,9 @@ class ModelEngine:
             st.broadcast_state(self.model)
         elif hasattr(st, "publish_state"):
             st.publish_state(self.model, is_chief)
+        # session creation is the one place where the host mirror is re-read from the device (a replica just
+        # received the chief's counter; a restore just set it)
+        self.model._host_step = int(self.model.store.global_step.item())
 
     # ---- running
     def _feed(self, feed_dict, key, default=None):

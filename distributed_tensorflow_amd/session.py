@@ -287,11 +287,19 @@ class MonitoredSession:
         self._stop = False
         self._closed = False
         self._recoveries = 0
+        self._step_cache: Optional[int] = None
+        self.step_reads = 0           # engine reads of global_step (at most one per run() and one per session creation)
         self.graph = getattr(engine, "graph", engine)
 
     # -- engine pass-throughs
     def global_step_value(self) -> int:
-        return int(self.engine.global_step_value())
+        """``global_step`` as of the end of the last ``run`` (or of session creation).  Every hook of one ``run``
+        shares ONE read of the engine's counter - TF fetches ``global_step`` once per ``run`` for all hooks too -
+        and the engine serves that read from its host mirror, so hooks cost no device synchronisation."""
+        if self._step_cache is None:
+            self._step_cache = int(self.engine.global_step_value())
+            self.step_reads += 1
+        return self._step_cache
 
     def describe_graph(self) -> str:
         d = getattr(self.engine, "describe", None)
@@ -321,6 +329,7 @@ class MonitoredSession:
         if self.is_chief and not restored and self.scaffold.init_fn is not None and first:
             self.scaffold.init_fn(self)
         self.engine.synchronize_state(self.is_chief)   # chief's values win everywhere; non-chiefs wait here
+        self._step_cache = None
         return restored
 
     def __enter__(self):
@@ -369,6 +378,7 @@ class MonitoredSession:
                 feed_dict = dict(feed_dict or {}, **req.feed_dict)
         hook_fetches = [f for f in extra if f is not None]
         results = self.engine.run({"caller": fetches, "hooks": hook_fetches}, feed_dict)
+        self._step_cache = None       # the run may have advanced the counter: the first hook that asks re-reads it
         hook_results = iter(results["hooks"])
         for h, f in zip(self.hooks, extra):
             h.after_run(ctx, SessionRunValues(next(hook_results) if f is not None else None))

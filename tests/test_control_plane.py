@@ -93,3 +93,71 @@ def test_barrier_and_heartbeat(server):
     time.sleep(0.12)
     c.heartbeat("worker:1")
     assert c.dead_members(0.1) == ["worker:0"] and c.dead_members(10) == []
+
+
+def test_folded_operations(server):
+    a, b = ControlClient("127.0.0.1", server.port), ControlClient("127.0.0.1", server.port)
+    # push_many / pop
+    a.push_many_json([("q/0", {"i": 0}), ("q/1", {"i": 1}), ("q/0", {"i": 2})])
+    assert b.pop_json("q/0")["i"] == 0 and b.pop_json("q/0")["i"] == 2 and b.pop_json("q/1")["i"] == 1
+    # take_many blocks until every key is there, returns in order, erases
+    got = []
+    t = threading.Thread(target=lambda: got.append(b.take_many_json(["r/0", "r/1"], timeout_s=5)))
+    t.start()
+    a.set_json("r/1", {"v": 1})
+    time.sleep(0.05)
+    assert not got
+    a.set_json("r/0", {"v": 0})
+    t.join(5)
+    assert got == [[{"v": 0}, {"v": 1}]]
+    with pytest.raises(ControlTimeout):
+        b.take_many(["r/0"], timeout_s=0.05)
+    # add_set: the reply carries the counter value it produced
+    assert a.add_set("gs", 1, "reply", b'{"global_step": %GS%}') == 1
+    assert a.add_set("gs", 1, "reply", b'{"global_step": %GS%}') == 2
+    assert b.take_json("reply") == {"global_step": 2}
+    assert a.add_set(None, 0, "plain", b"x") == 0 and b.get("plain") == b"x"
+    # wait_counter blocks server-side
+    done = []
+    t = threading.Thread(target=lambda: done.append(b.wait_counter("ready", 2, timeout_s=5)))
+    t.start()
+    a.add("ready", 1)
+    time.sleep(0.05)
+    assert not done
+    a.add("ready", 1)
+    t.join(5)
+    assert done == [2]
+    with pytest.raises(ControlTimeout):
+        b.wait_counter("ready", 3, timeout_s=0.05)
+    # clock_set_wait: publish and gate in one call
+    assert a.clock_set_wait("w", 0, 0, 1) == 0
+    assert b.clock_set_wait("w", 1, 1, 1, timeout_s=1) == 0
+    with pytest.raises(ControlTimeout):
+        b.clock_set_wait("w", 1, 2, 1, timeout_s=0.05)          # 2 - 0 > 1
+    assert a.clock_set_wait("w", 0, 1, None) == 1                # publish only
+    assert b.clock_set_wait("w", 1, 2, 1, timeout_s=1) == 1
+    n0 = a.calls
+    a.add("x", 1)
+    a.push_many([("q", b"1"), ("q", b"2")])
+    assert a.calls == n0 + 2
+
+
+def test_oversized_frame_drops_the_connection_not_the_server(server):
+    import socket
+    import struct
+    s = socket.create_connection(("127.0.0.1", server.port))
+    s.sendall(struct.pack("<IB", 0xFFFFFFF0, 1))          # a 4 GB "frame"
+    s.settimeout(5)
+    assert s.recv(16) == b""                               # closed by the server
+    s.close()
+    c = ControlClient("127.0.0.1", server.port)
+    assert c.add("alive", 1) == 1                          # the server still serves
+
+
+def test_many_short_connections_are_reaped(server):
+    for i in range(64):
+        c = ControlClient("127.0.0.1", server.port)
+        c.add("n", 1)
+        c.close()
+    c = ControlClient("127.0.0.1", server.port)
+    assert c.add("n", 0) == 64
