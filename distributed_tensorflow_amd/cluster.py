@@ -178,6 +178,35 @@ def replica_device_setter(ps_tasks: int = 0, ps_device: str = "/job:ps", worker_
     return DeviceSetter(worker_device, spec, ps_tasks, ps_strategy)
 
 
+# --------------------------------------------------------------------------- device plan
+def plan_devices(num_ps: int, num_workers: int, n_gpus: int, shared: bool = False) -> dict:
+    """Which device every task of a one-node cluster computes on.
+
+    ``n_gpus == 0``: everything on the CPU.  Otherwise worker ``i`` gets GPU ``i`` and ps task ``j`` GPU
+    ``num_workers + j``: RCCL accepts one rank per GPU, so no two tasks of a cluster may share one.  If the workers
+    alone do not fit, the cluster cannot run on this machine (``ValueError``).  If only the ps tasks do not fit
+    (1 ps + 8 workers on 8 GPUs), they get no GPU at all (``None``): they serve the control plane only and the
+    variables are owned by service threads inside the workers (``colocated``), sharded across the workers' HBMs.
+    ``shared=True`` (the gloo data plane: several ranks time-sharing one GPU on a test box) lifts the restriction and
+    wraps GPU indices around instead.
+
+    Returns ``{"worker": [...], "ps": [...], "colocated": bool}`` with ``"cpu"`` / ``"cuda:k"`` / ``None`` entries.
+    """
+    if n_gpus <= 0:
+        return {"worker": ["cpu"] * num_workers, "ps": ["cpu"] * num_ps, "colocated": num_ps == 0}
+    if shared:
+        return {"worker": ["cuda:%d" % (i % n_gpus) for i in range(num_workers)],
+                "ps": ["cuda:%d" % ((num_workers + j) % n_gpus) for j in range(num_ps)], "colocated": num_ps == 0}
+    if num_workers > n_gpus:
+        raise ValueError("%d worker tasks but %d GPU(s): RCCL needs one GPU per rank - start at most %d workers, or set "
+                         "DTF_COMM_BACKEND=gloo to let ranks time-share a GPU (rehearsal only)"
+                         % (num_workers, n_gpus, n_gpus))
+    if num_workers + num_ps <= n_gpus:
+        return {"worker": ["cuda:%d" % i for i in range(num_workers)],
+                "ps": ["cuda:%d" % (num_workers + j) for j in range(num_ps)], "colocated": num_ps == 0}
+    return {"worker": ["cuda:%d" % i for i in range(num_workers)], "ps": [None] * num_ps, "colocated": True}
+
+
 # --------------------------------------------------------------------------- server
 _CURRENT_SERVER = None
 
@@ -261,15 +290,31 @@ class Server:
         rport = int(env) if env else 20000 + (port * 7 + 13) % 20000
         return host, rport
 
+    def _device_plan(self) -> dict:
+        import torch
+        n = 0
+        if not self.config.get("force_cpu") and str(self.config.get("device", "")) != "cpu":
+            n = torch.cuda.device_count()           # counting does not initialise the GPU runtime
+        shared = os.environ.get("DTF_COMM_BACKEND", "") == "gloo"
+        return plan_devices(self.num_ps, self.num_workers, n, shared)
+
     def device(self):
+        """The device this task computes on (see :func:`plan_devices`).  A ps task without a GPU of its own gets the
+        CPU: it then only serves the control plane."""
         import torch
         if self.config.get("device"):
             return torch.device(self.config["device"])
-        if torch.cuda.is_available() and not self.config.get("force_cpu"):
-            n = torch.cuda.device_count()
-            idx = self.task_index if self.job_name == "worker" else self.num_workers + self.task_index
-            return torch.device("cuda", idx % n)
-        return torch.device("cpu")
+        d = self._device_plan()[self.job_name][self.task_index]
+        return torch.device(d if d is not None else "cpu")
+
+    def ps_tasks_have_devices(self) -> bool:
+        """False when the ps tasks of this cluster cannot each have a device next to the workers' (more tasks than
+        GPUs): the variables are then owned inside the worker processes."""
+        if self.num_ps == 0:
+            return False
+        if self.config.get("device"):
+            return True                            # an explicit device per task: the caller has planned the node
+        return not self._device_plan()["colocated"]
 
     # -- lifecycle
     def start(self):

@@ -71,32 +71,56 @@ class ModelEngine:
         return int(self.model.store.global_step.item())
 
     # ---- checkpoints
+    def _sharded_sync_save(self) -> bool:
+        """Synchronous replicas of a model large enough to be sharded: every replica writes its share of the files."""
+        st = self.model.strategy
+        return bool(getattr(st, "collective_checkpoint", False)) and st.world_size > 1 and not getattr(st, "replicated", True)
+
     def make_saver(self, max_to_keep: int = 5):
         st = self.model.strategy
+        store = self.model.store
+        if self._sharded_sync_save():
+            # one data shard per replica: whole variables (with their optimizer slots) dealt out byte-balanced
+            from .cluster import ByteBalancedPlacement
+            placement = ByteBalancedPlacement().assign([(v.name, v.numel * 4) for v in store.trainable], st.world_size)
+            return saver_mod.Saver(store, self.model.optimizer, max_to_keep=max_to_keep, placement=placement,
+                                   num_shards=st.world_size)
         placement = getattr(st, "placement", None) or {}
         shards = getattr(st, "num_owners", 1) if placement and not all(v == -1 for v in placement.values()) else 1
-        return saver_mod.Saver(self.model.store, self.model.optimizer, max_to_keep=max_to_keep,
+        return saver_mod.Saver(store, self.model.optimizer, max_to_keep=max_to_keep,
                                placement=placement if shards > 1 else None, num_shards=shards)
 
     def save_checkpoint(self, saver, save_path: str, step: int) -> str:
+        """One data shard per variable owner, index merged by the chief - whatever the strategy
+        (/root/reference/example.py:191: TF's sharded saver writes one shard per parameter-server task)."""
         st = self.model.strategy
         prefix = "%s-%d" % (save_path, int(step))
-        if hasattr(st, "save") and getattr(st, "placement_name", "") != "flat":
-            # asynchronous parameter servers: every owner writes its own shard, the chief merges
+        if hasattr(st, "save"):
+            # asynchronous parameter servers: every owner writes its own shard (variables and slots), the chief merges
             st.save(self.model, prefix, uuid.uuid4().hex)
             saver._record(prefix)
+            return prefix
+        if self._sharded_sync_save():
+            # every replica holds all variables (all-gathered each step) but only its shards of the optimizer slots:
+            # complete the slots over xGMI, then each replica writes the variables dealt to it - the device-to-host
+            # copies and the file writes run in parallel on all replicas instead of funnelling through the chief
+            st.gather_slots(self.model)
+            saver.save(save_path, global_step=step, only_shard=st.rank)
+            st.comm.barrier()
+            if st.rank == 0:
+                saver.finish_sharded_save(prefix)
+            st.comm.barrier()
             return prefix
         if hasattr(st, "gather_slots"):
             st.gather_slots(self.model)          # collective: every replica takes part
             if st.rank != 0:
                 return prefix
-        if hasattr(st, "pull"):
-            st.pull(self.model)                  # flat-sharded owners: fetch current values first
         return saver.save(save_path, global_step=step)
 
     def restore_checkpoint(self, saver, prefix: str) -> int:
         step = saver.restore(prefix)
         self.model._host_step = step
+        self.model._restored_from = prefix      # owners of an asynchronous cluster reload their shards from it too
         return step
 
     def synchronize_state(self, is_chief: bool):

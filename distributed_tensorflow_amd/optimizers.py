@@ -52,6 +52,12 @@ class Adam(Optimizer):
     def create_slots(self, store):
         store.slot("m")
         store.slot("v")
+        # TF's non-slot variables beta1_power / beta2_power START at beta (not 1) and are multiplied once per applied
+        # update, so a checkpoint written after t updates holds beta^(t+1) - what tf.train.AdamOptimizer expects to
+        # find when it resumes from one of these files.  (The kernels' own bias correction uses global_step.)
+        if not getattr(store, "_beta_powers_initialised", False) and getattr(store, "beta_powers", None) is not None:
+            store.beta_powers.copy_(initial_beta_powers(self, store.beta_powers.device))
+            store._beta_powers_initialised = True
 
     def apply(self, store, begin=0, end=None, grad_scale=1.0, grad=None, step=None):
         end = store.flat_len if end is None else end
@@ -91,6 +97,14 @@ class SGD(Optimizer):
         F.sgd_apply(store.flat, store.flat_grad, self.lr, mom, self.momentum, grad_scale, advance=store.global_step)
 
 
+def initial_beta_powers(optimizer, device):
+    """Initial value of the ``[beta1_power, beta2_power]`` pair for ``optimizer`` (ones for optimizers without them)."""
+    import torch
+    if isinstance(optimizer, Adam):
+        return torch.tensor([optimizer.beta1, optimizer.beta2], dtype=torch.float32, device=device)
+    return torch.ones(2, dtype=torch.float32, device=device)
+
+
 # TF 1.x class names (tf.train.*)
 AdamOptimizer = Adam
 GradientDescentOptimizer = SGD
@@ -104,6 +118,10 @@ _REGISTRY = {"adam": Adam, "sgd": SGD}
 
 
 def get(spec) -> Optimizer:
+    """Resolve ``compile(optimizer=...)``.  The strings are the Keras ones (/root/reference/example2.py:165).  The
+    reference pins keras==2.0.8 (/root/reference/requirements.txt:7), whose ``Adam`` signature still has
+    ``epsilon=1e-8`` - the same value as ``tf.train.AdamOptimizer()`` (/root/reference/example.py:168); the
+    ``epsilon=None -> K.epsilon() == 1e-7`` default only arrived in Keras 2.1.3.  So ``'adam'`` is ``Adam()``."""
     if isinstance(spec, Optimizer):
         return spec
     if isinstance(spec, str) and spec.lower() in _REGISTRY:

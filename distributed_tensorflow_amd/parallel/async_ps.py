@@ -9,26 +9,40 @@ budget.
 Re-designed for one MI355X node:
 
 * an *owner* holds ``[begin, end)`` ranges of the flat variable buffer together with the
-  optimizer slots for them, resident in its HBM; owners are either the ``ps`` tasks of the
-  cluster spec (separate processes, as in the reference) or - ``colocated`` - a service
-  thread inside every worker process, so that 8 workers on 8 GPUs shard the variables
-  across all eight HBMs;
-* per step a worker sends each owner ONE packed gradient message and receives ONE packed
-  parameter message back (``torch.distributed`` send/recv: RCCL over xGMI between GPUs,
-  gloo between CPU processes) instead of TF's one RecvTensor RPC per variable per direction;
-* the owner applies the fused apply-gradients kernel to its shard on arrival - updates from
-  different workers interleave freely across owners (Hogwild-style, ``use_locking=False``
-  semantics), each shard update itself is atomic;
-* *bounded staleness* (stale-synchronous parallel): every worker publishes its clock (number
-  of pushes) to the control plane and blocks before a step while
-  ``clock - min(all clocks) > max_staleness``.  ``max_staleness=None`` is the reference's
-  unbounded behaviour.  The observed staleness of every push (owner version at apply minus
-  owner version at the worker's last pull) is histogrammed.
+  optimizer slots for them, resident in its HBM, and applies the fused apply-gradients kernel
+  to its shard on arrival, on a stream of its own - updates from different workers interleave
+  freely across owners (Hogwild-style, ``use_locking=False`` semantics), each shard update
+  itself is atomic;
+* **colocated owners** (no ps tasks, or ps tasks without a GPU of their own): a service thread
+  inside every worker process owns 1/N of the flat buffer, so 8 workers on 8 GPUs shard the
+  variables across all eight HBMs.  The data plane is one-sided: a worker *puts* its gradient
+  shard into the owner's inbox slot and the owner puts fresh parameters into the worker's landing
+  zone through peer-mapped memory over xGMI (``peer_region.PeerRegion``: hipIpc on GPUs, POSIX
+  shared memory on CPUs).  No rendezvous between the two processes is needed, so owners can serve
+  workers in arrival order; two threads of a process sharing send/recv communicators cannot (their
+  blocking operations serialise on the communicator's stream and dead-lock across ranks);
+* **ps tasks as owners** (separate processes, as in the reference; whole variables placed
+  round-robin or byte-balanced): one packed gradient message to and one packed parameter message
+  from every owner per step over ``torch.distributed`` send/recv - RCCL between GPUs, gloo between
+  CPU processes - instead of TF's one RecvTensor RPC per variable per direction.  Each process
+  has exactly one thread on the data plane;
+* control traffic is folded: per step a worker makes one round trip per control server to queue its
+  requests, one to collect the replies (which carry the owner's version, the observed staleness
+  and the new ``global_step``), and - with a staleness bound - one to publish its clock and wait;
+* *bounded staleness* (stale-synchronous parallel): a worker that has completed ``c`` pushes may
+  start its next step only while ``c - min(all clocks) <= max_staleness``.  ``max_staleness=None``
+  is the reference's unbounded behaviour.  The observed staleness of every push (owner version at
+  apply minus owner version at the worker's last pull) is histogrammed;
+* checkpoints are written by the owners: every owner writes its own data shard (variables *and*
+  optimizer slots), the chief merges the index; on restore the owners reload their shards from the
+  files themselves, slots and ``beta*_power`` included.
 """
 from __future__ import annotations
 
+import json
 import threading
 import time
+import uuid
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -37,8 +51,6 @@ import torch.distributed as dist
 from ..control import ControlClient, ControlTimeout
 from ..variables import VariableStore
 
-_REQ_QUEUE = "ps/req"
-_NCCL_LOCK = threading.Lock()   # serialises the ENQUEUE of point-to-point ops of the two threads of a process
 
 
 def _ranges_numel(ranges: Sequence[Tuple[int, int]]) -> int:
@@ -69,6 +81,32 @@ def owner_ranges(store: VariableStore, placement: Dict[str, int], num_owners: in
     return [merge_ranges(r) for r in per]
 
 
+def owned_pieces(variables, ranges):
+    """Intersections of the variables with an owner's flat ranges.
+
+    ``variables``: ``(name, offset, numel, shape)`` in layout order.  Returns dicts with the variable (``name``,
+    ``shape``, ``offset``, ``numel``), the piece inside it (``lo``: first element of the variable covered, ``n``
+    elements) and ``shard_off``: where the piece starts in the owner's packed shard."""
+    out = []
+    off = 0
+    for b, e in ranges:
+        for name, voff, numel, shape in variables:
+            lo, hi = max(b, voff), min(e, voff + numel)
+            if lo < hi:
+                out.append({"name": name, "shape": tuple(shape), "offset": voff, "numel": numel, "lo": lo - voff,
+                            "n": hi - lo, "shard_off": off + lo - b})
+        off += e - b
+    return out
+
+
+def owner_of_element(all_ranges, index: int) -> int:
+    for j, rs in enumerate(all_ranges):
+        for b, e in rs:
+            if b <= index < e:
+                return j
+    raise ValueError("flat index %d belongs to no owner" % index)
+
+
 def _pack(flat: torch.Tensor, ranges, out: torch.Tensor) -> torch.Tensor:
     if len(ranges) == 1:
         b, e = ranges[0]
@@ -88,21 +126,37 @@ def _unpack(buf: torch.Tensor, flat: torch.Tensor, ranges):
         pos += e - b
 
 
-# --------------------------------------------------------------------------- data-plane helper
-class _P2P:
-    """send/recv between global ranks with the loop-back (same process) case short-circuited.
+def _numel(shape) -> int:
+    n = 1
+    for s in shape:
+        n *= int(s)
+    return n
 
-    RCCL matches the sends and receives of a pair of ranks purely by issue order (message tags are ignored), and a
-    process here has two threads talking to the same peers - the worker thread (gradients out, parameters in) and,
-    when owners are colocated, the owner thread (gradients in, parameters out).  Each direction therefore gets its
-    own communicator: on ``push`` only worker threads send and only owner threads receive, on ``pull`` the reverse,
-    so every (source, destination) pair of a communicator carries one strictly ordered stream.
+
+# --------------------------------------------------------------------------- data plane: torch.distributed send/recv
+_TAG_PUSH, _TAG_PULL, _TAG_INIT = 11, 12, 13
+
+
+def _staged(t: torch.Tensor) -> bool:
+    """GPU tensor on the gloo backend (ranks time-sharing one GPU): moved through host memory explicitly, see
+    ``Communicator._staged``."""
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
+class _P2P:
+    """send/recv between the global ranks of a cluster whose owners are ps tasks.
+
+    Every process has ONE thread on the data plane (a worker's training thread, a ps task's service loop), and each
+    direction has its own process group: on ``push`` only workers send and only owners receive, on ``pull`` the
+    reverse, so every (source, destination) pair of a communicator carries one strictly ordered stream.  RCCL matches
+    the operations of a pair purely by issue order on one communicator, and PyTorch routes an operation issued inside
+    a batch through the group-wide communicator but a lone one through a two-rank communicator of its own - so over
+    RCCL *every* operation here is issued as a batch (of one, if need be): both ends then always meet on the same
+    communicator.
     """
 
     def __init__(self, rank: int):
         self.rank = rank
-        self.mail: Dict[Tuple[int, int], List[torch.Tensor]] = {}
-        self.cv = threading.Condition()
         self.push_group = None      # worker -> owner (gradients, initial values)
         self.pull_group = None      # owner -> worker (parameters)
 
@@ -115,104 +169,86 @@ class _P2P:
     def _group(self, tag: int):
         return self.pull_group if tag == _TAG_PULL else self.push_group
 
+    def _issue(self, ops):
+        """Start the operations (all of one group); returns the work handles."""
+        if not ops:
+            return []
+        if dist.get_backend() == "nccl":
+            return dist.batch_isend_irecv(ops)
+        return [op.op(op.tensor, op.peer, group=op.group, tag=op.tag) for op in ops]
+
     def send(self, t: torch.Tensor, dst: int, tag: int):
-        if dst == self.rank:
-            with self.cv:
-                self.mail.setdefault((tag, 0), []).append(t.clone())
-                self.cv.notify_all()
-            return
-        if _staged(t):
-            t = t.cpu()
-        with _NCCL_LOCK:
-            w = dist.isend(t, dst=dst, tag=tag, group=self._group(tag))
-        w.wait()
+        self.exchange([(t, dst, tag)], [])
 
     def recv(self, t: torch.Tensor, src: int, tag: int):
-        if src == self.rank:
-            with self.cv:
-                while not self.mail.get((tag, 0)):
-                    self.cv.wait()
-                t.copy_(self.mail[(tag, 0)].pop(0))
-            return
-        h = torch.empty(t.shape, dtype=t.dtype) if _staged(t) else t
-        with _NCCL_LOCK:
-            w = dist.irecv(h, src=src, tag=tag, group=self._group(tag))
-        w.wait()
-        if h is not t:
-            t.copy_(h)
-
+        self.exchange([], [(t, src, tag)])
 
     def exchange(self, sends, recvs):
         """Post every send ``(tensor, dst, tag)`` and receive ``(tensor, src, tag)`` at once, then wait for all.
 
-        A worker must never block on one owner before it has posted its traffic to the others: owners
-        serve workers in arrival order, so blocking sends issued one owner at a time can form a cycle.
-        On NCCL the operations are issued as one group (they progress concurrently on the stream).
+        A worker must never block on one owner before it has posted its traffic to the others: owners serve
+        workers in arrival order, so blocking sends issued one owner at a time can form a cycle.  Over RCCL the
+        sends form one group and the receives another (a batch may not mix communicators); the operations of a
+        group progress independently of each other.
         """
-        local_recvs = []
-        send_ops, recv_ops = [], []
-        for t, dst, tag in sends:
-            if dst == self.rank:
-                with self.cv:
-                    self.mail.setdefault((tag, 0), []).append(t.clone())
-                    self.cv.notify_all()
-            else:
-                send_ops.append(dist.P2POp(dist.isend, t.cpu() if _staged(t) else t, dst, group=self._group(tag), tag=tag))
+        by_group: Dict[int, list] = {}
         staged = []
+        keep = []
+        for t, dst, tag in sends:
+            h = t.cpu() if _staged(t) else t
+            keep.append(h)
+            by_group.setdefault(id(self._group(tag)), []).append(dist.P2POp(dist.isend, h, dst, group=self._group(tag), tag=tag))
         for t, src, tag in recvs:
-            if src == self.rank:
-                local_recvs.append((t, tag))
-            else:
-                h = t
-                if _staged(t):
-                    h = torch.empty(t.shape, dtype=t.dtype)
-                    staged.append((t, h))
-                recv_ops.append(dist.P2POp(dist.irecv, h, src, group=self._group(tag), tag=tag))
+            h = t
+            if _staged(t):
+                h = torch.empty(t.shape, dtype=t.dtype)
+                staged.append((t, h))
+            by_group.setdefault(id(self._group(tag)), []).append(dist.P2POp(dist.irecv, h, src, group=self._group(tag), tag=tag))
         works = []
-        with _NCCL_LOCK:           # one batch per communicator (a batch may not mix groups)
-            if send_ops:
-                works += dist.batch_isend_irecv(send_ops)
-            if recv_ops:
-                works += dist.batch_isend_irecv(recv_ops)
-        for t, tag in local_recvs:
-            with self.cv:
-                while not self.mail.get((tag, 0)):
-                    self.cv.wait()
-                t.copy_(self.mail[(tag, 0)].pop(0))
+        for ops in by_group.values():
+            works += self._issue(ops)
         for w in works:
             w.wait()
         for t, h in staged:
             t.copy_(h)
 
 
-def _staged(t: torch.Tensor) -> bool:
-    """GPU tensor on the gloo backend (ranks time-sharing one GPU): moved through host memory explicitly, see
-    ``Communicator._staged``."""
-    return t.is_cuda and dist.get_backend() == "gloo"
-
-
-_TAG_PUSH, _TAG_PULL, _TAG_INIT = 11, 12, 13
-
-
 # --------------------------------------------------------------------------- owner / parameter-server side
 class ParameterServerService:
-    """Owner of a set of flat ranges: serves init / pushpull / pull / save / restore / shutdown."""
+    """Owner of a set of flat ranges: serves init / pushpull / pull / save / restore / stats / shutdown.
+
+    Two data planes: ``region`` (a :class:`~.peer_region.PeerRegion` shared with the workers: colocated owners) or
+    ``p2p`` (``torch.distributed`` send/recv: ps tasks).  Layout of a region, in floats, with ``F`` the flat length
+    and ``S`` the shard length ``F / owners``:
+
+    * ``[w*S, (w+1)*S)``          inbox slot of worker ``w`` (its gradient - or initial values - for this owner);
+    * ``[F + b, F + e)``          landing zone: parameters of the owner whose flat range is ``[b, e)``;
+    * ``[2F + o, ...)``           checkpoint staging: pieces of variables this rank writes, at their flat offset ``o``.
+    """
 
     def __init__(self, server=None, owner_index: Optional[int] = None, control: Optional[ControlClient] = None,
-                 rank: Optional[int] = None, device=None, p2p: Optional[_P2P] = None, num_workers: Optional[int] = None,
-                 worker_rank_of=None):
+                 control0: Optional[ControlClient] = None, rank: Optional[int] = None, device=None,
+                 p2p: Optional[_P2P] = None, region=None, num_workers: Optional[int] = None, worker_rank_of=None,
+                 num_owners: Optional[int] = None, ns: str = "ps"):
         self.server = server
+        self.ns = ns                        # key prefix: "ps" for ps tasks, "co" for owners colocated with workers
         self.owner_index = owner_index if owner_index is not None else server.task_index
         if control is None:
             host, port = server.control_address(self.owner_index)
             control = ControlClient(host if host not in ("0.0.0.0",) else "127.0.0.1", port)
-        self.cp = control
+        self.cp = control                   # this owner's request queue and replies live here
+        if control0 is None:
+            host, port = server.control_address(0)
+            control0 = ControlClient(host if host not in ("0.0.0.0",) else "127.0.0.1", port)
+        self.cp0 = control0                 # cluster-wide counters and barriers live on the first control server
         self.device = device if device is not None else server.device()
         self.rank = rank if rank is not None else server.rank
         self.num_workers = num_workers if num_workers is not None else server.num_workers
+        self.num_owners = num_owners if num_owners is not None else max(server.num_ps, 1)
         self.worker_rank_of = worker_rank_of or (lambda i: server.worker_rank(i))
         self.p2p = p2p
-        self.queue = "%s/%d" % (_REQ_QUEUE, self.owner_index)
+        self.region = region
+        self.queue = "%s/req/%d" % (self.ns, self.owner_index)
         self.ranges: List[Tuple[int, int]] = []
         self.var = self.grad = None
         self.slots: Dict[str, torch.Tensor] = {}
@@ -221,6 +257,8 @@ class ParameterServerService:
         self.opt = None
         self.staleness_hist: Dict[int, int] = {}
         self._owns_group = False
+        self.stream = None
+        self.error: Optional[BaseException] = None
 
     # a tiny VariableStore look-alike so Optimizer.apply works on the owned shard
     class _Shard:
@@ -241,9 +279,8 @@ class ParameterServerService:
     def _join_data_plane(self):
         if dist.is_initialized():
             return
-        from .comm import init_process_group
+        from .comm import init_process_group, pick_backend
         host, port = self.server.rendezvous_address()
-        from .comm import pick_backend
         backend = pick_backend(self.device)
         init_process_group(backend, rank=self.rank, world_size=self.server.world_size, master_addr=host,
                            master_port=port, device=self.device if backend == "nccl" else None)
@@ -251,38 +288,95 @@ class ParameterServerService:
 
     def _configure(self, layout: dict):
         from .. import optimizers
-        self.ranges = [tuple(r) for r in layout["ranges"][self.owner_index]]
+        self.layout = layout
+        self.all_ranges = [[tuple(r) for r in rs] for rs in layout["ranges"]]
+        self.ranges = self.all_ranges[self.owner_index]
+        self.variables = [(n, int(o), int(k), tuple(s)) for n, o, k, s in layout["variables"]]
+        self.flat_len = int(layout["flat_len"])
         n = _ranges_numel(self.ranges)
         self.var = torch.zeros(max(n, 1), dtype=torch.float32, device=self.device)
-        self.grad = torch.zeros_like(self.var)
+        self.grad = torch.zeros_like(self.var) if self.region is None else None
         self.step_t = torch.zeros(1, dtype=torch.int64, device=self.device)
-        self.beta_powers = torch.ones(2, dtype=torch.float32, device=self.device)
         o = layout["optimizer"]
         self.opt = optimizers.Adam(**o["args"]) if o["name"] == "Adam" else optimizers.SGD(**o["args"])
+        self.beta_powers = optimizers.initial_beta_powers(self.opt, self.device)
         self.shard = ParameterServerService._Shard(self)
         self.opt.create_slots(self.shard)
         self.n = n
+        self.pieces = owned_pieces(self.variables, self.ranges)
+        if self.region is not None:
+            self.slot_len = self.flat_len // self.num_owners
+
+    # -- transport
+    def _incoming(self, worker: int, wr, tag: int) -> torch.Tensor:
+        """The tensor worker ``worker`` sent for this request (gradient, or initial values)."""
+        if self.region is not None:
+            b = worker * self.slot_len
+            return self.region.local[b:b + self.n]        # written and synchronised before the request was queued
+        buf = self.grad if tag == _TAG_PUSH else self.var
+        self.p2p.recv(buf[:self.n], wr, tag)
+        return buf[:self.n]
+
+    def _send_params(self, worker: int, wr):
+        if self.region is not None:
+            b = self.flat_len + self.ranges[0][0]
+            self.region.put(worker, b, self.var[:self.n])
+            self.region.sync()                             # complete and visible before the reply is published
+        else:
+            self.p2p.send(self.var[:self.n], wr, _TAG_PULL)
+
+    def _reply(self, worker: int, staleness: int, count_step: bool):
+        body = '{"version": %d, "global_step": %s, "staleness": %d}' % (
+            self.version, "%GS%" if count_step else "-1", staleness)
+        self.cp.add_set("global_step" if count_step else None, 1 if count_step else 0,
+                        "%s/reply/%d/%d" % (self.ns, self.owner_index, worker), body.encode())
 
     def serve(self):
-        """Request loop; returns after a ``shutdown`` request."""
-        # the chief posts the layout; a cluster that trains without its ps tasks (synchronous replicas)
-        # only ever sends "shutdown"
+        """Request loop; returns after a ``shutdown`` request.  An exception ends the loop and is kept in ``error``
+        (and re-raised for a ps task, whose process then exits non-zero)."""
+        try:
+            self._serve()
+        except BaseException as e:      # noqa: BLE001 - the worker thread of a colocated owner must learn about it
+            self.error = e
+            try:
+                self.cp0.set("%s/failed/%d" % (self.ns, self.owner_index), repr(e).encode())
+            except Exception:
+                pass
+            raise
+
+    def _serve(self):
+        # the chief posts the layout; a cluster that trains without its ps tasks (synchronous replicas,
+        # colocated owners) only ever sends "shutdown"
         layout = None
         while layout is None:
             try:
-                layout = self.cp.get_json("ps/layout", timeout_s=0.5)
+                layout = self.cp.get_json("%s/layout/%d" % (self.ns, self.owner_index), timeout_s=0.5)
             except ControlTimeout:
                 if self.cp.qlen(self.queue) > 0:
                     req = self.cp.pop_json(self.queue, timeout_s=1.0)
                     if req.get("op") == "shutdown":
-                        self.cp.add("ps/stopped", 1)
+                        self.cp0.add(self.ns + "/stopped", 1)
                         return
-        if self.p2p is None:
+        if self.device.type == "cuda":
+            torch.cuda.set_device(self.device)
+            self.stream = torch.cuda.Stream(device=self.device)     # applies overlap the worker's compute stream
+        if self.region is None and self.p2p is None:
             self._join_data_plane()      # only clusters that use their ps tasks put them on the data plane
             self.p2p = _P2P(self.rank)
             self.p2p.make_direction_groups()
-        self._configure(layout)
-        self.cp.add("ps/ready", 1)
+        ctx = torch.cuda.stream(self.stream) if self.stream is not None else _NullContext()
+        with ctx:
+            self._configure(layout)
+            self.cp0.add(self.ns + "/ready", 1)
+            self._loop()
+        self.cp0.add(self.ns + "/stopped", 1)
+        if self._owns_group and dist.is_initialized():
+            try:
+                dist.destroy_process_group()
+            except Exception:
+                pass
+
+    def _loop(self):
         while True:
             try:
                 req = self.cp.pop_json(self.queue, timeout_s=5.0)
@@ -290,100 +384,141 @@ class ParameterServerService:
                 continue
             op = req["op"]
             if op == "shutdown":
-                break
-            wr = self.worker_rank_of(req["worker"]) if "worker" in req else None
+                return
+            w = req.get("worker")
+            wr = self.worker_rank_of(w) if w is not None else None
             if op == "init":
                 if self.n:
-                    self.p2p.recv(self.var[:self.n], wr, _TAG_INIT)
+                    src = self._incoming(w, wr, _TAG_INIT)
+                    if src.data_ptr() != self.var.data_ptr():
+                        self.var[:self.n].copy_(src)
+                for s in self.slots.values():
+                    s.zero_()
                 self.version = 0
                 self.step_t.fill_(int(req.get("global_step", 0)))
-                self.cp.add("ps/init_done", 1)
+                from .. import optimizers
+                self.beta_powers.copy_(optimizers.initial_beta_powers(self.opt, self.device))
+                if self.stream is not None:
+                    self.stream.synchronize()
+                self.cp0.add(self.ns + "/init_done", 1)
             elif op == "pushpull":
                 if self.n:
-                    self.p2p.recv(self.grad[:self.n], wr, _TAG_PUSH)
-                    self.opt.apply(self.shard, 0, self.n, grad_scale=1.0, grad=self.grad, step=self.step_t)
+                    g = self._incoming(w, wr, _TAG_PUSH)
+                    self.opt.apply(self.shard, 0, self.n, grad_scale=1.0, grad=g, step=self.step_t)
                     self.opt.finish_step(self.shard)
                 st = self.version - int(req.get("version", self.version))
                 self.staleness_hist[st] = self.staleness_hist.get(st, 0) + 1
                 self.version += 1
-                if self.owner_index == 0:
-                    gs = self.cp.add("global_step", 1)
+                if self.region is not None:
+                    if self.n:
+                        self._send_params(w, wr)
+                    self._reply(w, st, self.owner_index == 0)
                 else:
-                    gs = -1
-                self.cp.set_json("ps/reply/%d/%d" % (self.owner_index, req["worker"]),
-                                 {"version": self.version, "global_step": gs, "staleness": st})
-                if self.n:
-                    self.p2p.send(self.var[:self.n], wr, _TAG_PULL)
+                    # the reply first: the worker reads it after its receive has completed anyway, and a send
+                    # that waits for the peer must not delay it
+                    self._reply(w, st, self.owner_index == 0)
+                    if self.n:
+                        self._send_params(w, wr)
             elif op == "pull":
-                self.cp.set_json("ps/reply/%d/%d" % (self.owner_index, req["worker"]),
-                                 {"version": self.version, "global_step": -1, "staleness": 0})
-                if self.n:
-                    self.p2p.send(self.var[:self.n], wr, _TAG_PULL)
+                if self.region is not None:
+                    if self.n:
+                        self._send_params(w, wr)
+                    self._reply(w, 0, False)
+                else:
+                    self._reply(w, 0, False)
+                    if self.n:
+                        self._send_params(w, wr)
             elif op == "save":
                 self._save(req)
             elif op == "restore":
                 self._restore(req)
             elif op == "stats":
-                self.cp.set_json("ps/stats/%d" % self.owner_index,
+                self.cp.set_json("%s/stats/%d" % (self.ns, self.owner_index),
                                  {"version": self.version, "staleness": {str(k): v for k, v in self.staleness_hist.items()}})
-        self.cp.add("ps/stopped", 1)
-        if self._owns_group and dist.is_initialized():
-            try:
-                dist.destroy_process_group()
-            except Exception:
-                pass
 
-    # sharded checkpoint: this owner writes data shard `owner_index` (var ranges + slots as flat tensors)
+    # -- checkpoints
     def _save(self, req):
+        """This owner's part of a checkpoint: data shard ``owner_index`` with the variables this owner *writes* - those
+        whose first element it owns - and their optimizer slots.  A variable that straddles owners (flat sharding)
+        is first assembled in the writer's staging area: every owner puts the pieces it holds there."""
         from ..saver import BundleWriter
+        token = req["token"]
+        gather = bool(req.get("gather"))
+        if gather and self.region is None:
+            raise RuntimeError("variables split across ps tasks cannot be checkpointed by their owners")
+        kinds = [("", None)] + [(suffix, slot) for slot, suffix in sorted(req["slots"].items()) if slot in self.slots]
+        stage = 2 * self.flat_len
         w = BundleWriter(req["prefix"], req["num_shards"], only_shard=self.owner_index)
-        for name, b, e, off in req["tensors"][str(self.owner_index)]:
-            shape = req["shapes"][name]
-            w.add(name, self.var[off:off + (e - b)][:_numel(shape)].reshape(shape), self.owner_index)
-            for slot, suffix in req["slots"].items():
-                if slot in self.slots:
-                    w.add("%s/%s" % (name, suffix), self.slots[slot][off:off + (e - b)][:_numel(shape)].reshape(shape),
-                          self.owner_index)
-        if self.owner_index == 0:
-            w.add("global_step", torch.tensor(int(req["global_step"]), dtype=torch.int64), 0)
-            if req["optimizer"] == "Adam":
-                w.add("beta1_power", self.beta_powers[0], 0)
-                w.add("beta2_power", self.beta_powers[1], 0)
-        w.finish()
-        self.cp.add("ps/save_done/%s" % req["token"], 1)
+        try:
+            for suffix, slot in kinds:
+                src = self.var if slot is None else self.slots[slot]
+                if gather:
+                    for p in self.pieces:
+                        if p["n"] != p["numel"]:
+                            writer = owner_of_element(self.all_ranges, p["offset"])
+                            self.region.put(writer, stage + p["offset"] + p["lo"], src[p["shard_off"]:p["shard_off"] + p["n"]])
+                    self.region.sync()
+                    self.cp0.barrier("%s/ckpt/%s/%s/in" % (self.ns, token, suffix), self.num_owners, timeout_s=600)
+                for p in self.pieces:
+                    if p["lo"] != 0:
+                        continue                                   # written by the owner of the variable's first element
+                    if p["n"] == p["numel"]:
+                        t = src[p["shard_off"]:p["shard_off"] + p["numel"]]
+                    else:
+                        t = self.region.local[stage + p["offset"]:stage + p["offset"] + p["numel"]]
+                    name = p["name"] if not suffix else "%s/%s" % (p["name"], suffix)
+                    w.add(name, t.reshape(p["shape"]), self.owner_index)
+                if gather:
+                    self.cp0.barrier("%s/ckpt/%s/%s/out" % (self.ns, token, suffix), self.num_owners, timeout_s=600)
+            if self.owner_index == 0:
+                w.add("global_step", torch.tensor(int(req["global_step"]), dtype=torch.int64), 0)
+                if req["optimizer"] == "Adam":
+                    w.add("beta1_power", self.beta_powers[0], 0)
+                    w.add("beta2_power", self.beta_powers[1], 0)
+            w.finish()
+        except Exception:
+            w.abort()
+            raise
+        self.cp0.add("%s/save_done/%s" % (self.ns, token), 1)
 
     def _restore(self, req):
+        """Reload this owner's pieces - variables, optimizer slots, ``beta*_power``, the step - from a checkpoint."""
         from ..saver import BundleReader
         with BundleReader(req["prefix"]) as r:
-            for name, b, e, off in req["tensors"][str(self.owner_index)]:
-                n = _numel(req["shapes"][name])
-                self.var[off:off + n].copy_(r.get_tensor(name).reshape(-1))
+            for p in self.pieces:
+                sl = slice(p["shard_off"], p["shard_off"] + p["n"])
+                self.var[sl].copy_(r.get_tensor(p["name"]).reshape(-1)[p["lo"]:p["lo"] + p["n"]])
                 for slot, suffix in req["slots"].items():
-                    key = "%s/%s" % (name, suffix)
+                    key = "%s/%s" % (p["name"], suffix)
                     if r.has_tensor(key):
-                        self.shard.slot(slot)[off:off + n].copy_(r.get_tensor(key).reshape(-1))
+                        self.shard.slot(slot)[sl].copy_(r.get_tensor(key).reshape(-1)[p["lo"]:p["lo"] + p["n"]])
             if r.has_tensor("global_step"):
                 self.step_t.fill_(int(r.get_tensor("global_step").item()))
             if r.has_tensor("beta1_power"):
                 self.beta_powers[0] = r.get_tensor("beta1_power")
                 self.beta_powers[1] = r.get_tensor("beta2_power")
-        self.cp.add("ps/restore_done/%s" % req["token"], 1)
+        self.version = 0
+        if self.stream is not None:
+            self.stream.synchronize()
+        self.cp0.add("%s/restore_done/%s" % (self.ns, req["token"]), 1)
 
 
-def _numel(shape) -> int:
-    n = 1
-    for s in shape:
-        n *= int(s)
-    return n
+class _NullContext:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
 
 
 # --------------------------------------------------------------------------- worker side
 class AsyncPSStrategy:
     """Worker-side strategy for ``Sequential.compile(strategy=...)``.
 
-    ``server``: the task's :class:`~distributed_tensorflow_amd.cluster.Server`.  With ps tasks in the
-    cluster they are the owners; with ``colocated=True`` (or no ps tasks) every worker also runs an owner
-    service thread and the variables are flat-sharded over all workers.
+    ``server``: the task's :class:`~distributed_tensorflow_amd.cluster.Server`.  With ps tasks that can each have a
+    device of their own they are the owners; otherwise (no ps tasks, or more tasks than GPUs) - or with
+    ``colocated=True`` - every worker also runs an owner service thread, the variables are flat-sharded over all
+    workers and the ps tasks only serve the control plane.
     """
 
     def __init__(self, server, max_staleness: Optional[int] = None, placement="round_robin",
@@ -392,9 +527,14 @@ class AsyncPSStrategy:
         self.max_staleness = max_staleness
         self.worker_index = server.task_index
         self.num_workers = server.num_workers
-        self.colocated = (server.num_ps == 0) if colocated is None else colocated
+        if colocated is None:
+            colocated = server.num_ps == 0 or not server.ps_tasks_have_devices()
+        self.colocated = bool(colocated)
         self.num_owners = self.num_workers if self.colocated else server.num_ps
+        if placement == "flat" and not self.colocated:
+            raise ValueError("flat sharding needs colocated owners (ps tasks own whole variables)")
         self.placement_name = "flat" if self.colocated else placement
+        self.ns = "co" if self.colocated else "ps"      # ps tasks that only serve the control plane keep "ps/..."
         self.timeout_s = timeout_s
         self.world_size = 1           # gradients are NOT averaged across workers in async mode
         self.rank = 0
@@ -402,21 +542,73 @@ class AsyncPSStrategy:
         self.versions: List[int] = []
         self.staleness_hist: Dict[int, int] = {}
         self.last_global_step = 0
+        self._service = None
         self._service_thread = None
         self._cps: List[ControlClient] = []
         self._staging: Dict = {}
+        self.region = None
+        self.p2p = None
 
     def var_alignment(self) -> int:
         return 64 * max(1, self.num_owners)
 
+    # -- control plane helpers
+    def _distinct_cps(self) -> List[Tuple[ControlClient, List[int]]]:
+        """(client, owners whose queue lives on that control server), one entry per distinct server."""
+        out: List[Tuple[ControlClient, List[int]]] = []
+        for j, c in enumerate(self._cps):
+            for cc, js in out:
+                if cc is c:
+                    js.append(j)
+                    break
+            else:
+                out.append((c, [j]))
+        return out
+
+    def control_calls(self) -> int:
+        """Control-plane round trips this worker has made so far (all of its clients)."""
+        return sum(c.calls for c, _ in self._distinct_cps())
+
+    def _post(self, op: str, extra=None, owners=None):
+        """Queue one request per owner: one round trip per control server."""
+        for c, js in self._distinct_cps():
+            items = []
+            for j in js:
+                if owners is not None and j not in owners:
+                    continue
+                req = {"op": op, "worker": self.worker_index}
+                if extra is not None:
+                    req.update(extra(j) if callable(extra) else extra)
+                items.append(("%s/req/%d" % (self.ns, j), req))
+            if items:
+                c.push_many_json(items)
+
+    def _collect(self) -> List[dict]:
+        """The owners' replies to this worker's last requests, in owner order: one round trip per control server."""
+        reps: List[Optional[dict]] = [None] * self.num_owners
+        for c, js in self._distinct_cps():
+            got = c.take_many_json(["%s/reply/%d/%d" % (self.ns, j, self.worker_index) for j in js], timeout_s=self.timeout_s)
+            for j, r in zip(js, got):
+                reps[j] = r
+        self._check_service()
+        return reps
+
+    def _check_service(self):
+        svc = self._service
+        if svc is not None and svc.error is not None:
+            raise RuntimeError("the owner service of this worker failed: %r" % (svc.error,))
+
+    def _wait_counter(self, key: str, n: int):
+        self.cp0.wait_counter(key, n, timeout_s=self.timeout_s)
+
     # -- topology
     def prepare(self, model):
-        from .comm import init_process_group
+        from .comm import init_process_group, pick_backend
         from ..cluster import PLACEMENTS
         srv = self.server
         store = model.store
         dev = store.device
-        # control plane: one client per owner's server (colocated: the chief's server hosts every queue)
+        # control plane: one client per owner's server (colocated: the first server hosts every queue)
         if self.colocated:
             host, port = srv.control_address(0)
             self._cps = [ControlClient(host, port, self.timeout_s)] * self.num_owners
@@ -424,60 +616,88 @@ class AsyncPSStrategy:
             self._cps = [ControlClient(*srv.control_address(j), timeout_s=self.timeout_s) for j in range(self.num_owners)]
         self.cp0 = self._cps[0]
         self.my_rank = self.worker_index if self.colocated else srv.rank
-        self.p2p = _P2P(self.my_rank)
-        owner_rank = (lambda j: j) if self.colocated else srv.ps_rank
-        self.owner_rank = owner_rank
+        self.owner_rank = (lambda j: j) if self.colocated else srv.ps_rank
         # layout
         variables = [(v.name, v.numel * 4) for v in store.trainable]
         placement = PLACEMENTS[self.placement_name]().assign(variables, self.num_owners)
         self.placement = placement
         self.ranges = owner_ranges(store, placement, self.num_owners)
+        self.flat_len = store.flat_len
         opt = model.optimizer
         opt_desc = {"name": opt.name, "args": ({"lr": opt.lr, "beta_1": opt.beta1, "beta_2": opt.beta2,
                                                 "epsilon": opt.epsilon} if opt.name == "Adam"
                                                else {"lr": opt.lr, "momentum": opt.momentum})}
+        self.var_table = [(v.name, v.offset, v.numel, list(v.shape)) for v in store.trainable]
+        # does any variable straddle two owners?  (then a checkpoint assembles it in its writer's staging area)
+        self.gather = any(p["n"] != p["numel"] for j in range(self.num_owners)
+                          for p in owned_pieces(self.var_table, self.ranges[j]))
         if self.colocated:
+            # one-sided data plane: inbox slots + landing zone + checkpoint staging, three flat images per rank
+            from .peer_region import PeerRegion
+            self.slot_len = store.flat_len // self.num_owners
+            self.region = PeerRegion(self.worker_index, self.num_workers, 3 * store.flat_len, dev, self.cp0,
+                                     name="co/region", timeout_s=self.timeout_s)
             svc = ParameterServerService(server=srv, owner_index=self.worker_index,
                                          control=ControlClient(*srv.control_address(0), timeout_s=self.timeout_s),
-                                         rank=self.my_rank, device=dev, p2p=self.p2p, num_workers=self.num_workers,
-                                         worker_rank_of=lambda i: i)
+                                         control0=ControlClient(*srv.control_address(0), timeout_s=self.timeout_s),
+                                         rank=self.my_rank, device=dev, region=self.region,
+                                         num_workers=self.num_workers, worker_rank_of=lambda i: i,
+                                         num_owners=self.num_owners, ns=self.ns)
             self._service = svc
-            self._service_thread = threading.Thread(target=svc.serve, name="dtf-owner-%d" % self.worker_index,
+            self._service_thread = threading.Thread(target=self._run_service, name="dtf-owner-%d" % self.worker_index,
                                                     daemon=True)
         if srv.is_chief:
-            layout = {"ranges": self.ranges, "optimizer": opt_desc, "flat_len": store.flat_len}
-            for j in sorted(set(range(self.num_owners))):
-                self._cps[j].set_json("ps/layout", layout)
-        # data plane (after the layout is out: ps tasks join the process group once they have it)
-        if not dist.is_initialized():
-            host, port = srv.rendezvous_address()
-            from .comm import pick_backend
-            backend = pick_backend(dev)
-            world = self.num_workers if self.colocated else srv.world_size
-            rank = self.worker_index if self.colocated else srv.rank
-            init_process_group(backend, rank=rank, world_size=world, master_addr=host, master_port=port,
-                               device=dev if backend == "nccl" else None)
-        self.p2p.make_direction_groups()
+            layout = {"ranges": self.ranges, "optimizer": opt_desc, "flat_len": store.flat_len,
+                      "variables": self.var_table}
+            for c, js in self._distinct_cps():
+                for j in js:
+                    c.set_json("%s/layout/%d" % (self.ns, j), layout)
+        if not self.colocated:
+            # data plane (after the layout is out: ps tasks join the process group once they have it)
+            if not dist.is_initialized():
+                host, port = srv.rendezvous_address()
+                backend = pick_backend(dev)
+                init_process_group(backend, rank=srv.rank, world_size=srv.world_size, master_addr=host,
+                                   master_port=port, device=dev if backend == "nccl" else None)
+            self.p2p = _P2P(self.my_rank)
+            self.p2p.make_direction_groups()
         if self._service_thread is not None:
             self._service_thread.start()
+            import atexit
+            atexit.register(self.close)       # the service thread must be gone before the interpreter tears down
         # chief initialises the owners, everybody else waits (chief-initialises / others-wait)
-        if srv.is_chief:
-            self._wait_counter("ps/ready", self.num_owners)
-            gs0 = int(store.global_step.item())
-            for j in range(self.num_owners):
-                self._cps[j].push_json("%s/%d" % (_REQ_QUEUE, j), {"op": "init", "worker": self.worker_index,
-                                                                  "global_step": gs0})
-                if _ranges_numel(self.ranges[j]):
-                    self.p2p.send(_pack(store.flat, self.ranges[j], self._stage(j, store)).contiguous(),
-                                  owner_rank(j), _TAG_INIT)
-            self._wait_counter("ps/init_done", self.num_owners)
-            self.cp0.add("global_step", gs0)
-            self.cp0.set("ps/initialized", b"1")
-        else:
-            self.cp0.get("ps/initialized", timeout_s=self.timeout_s)
         self.versions = [0] * self.num_owners
+        if srv.is_chief:
+            self._wait_counter(self.ns + "/ready", self.num_owners)
+            self._init_owners(store, int(store.global_step.item()))
+            self.cp0.set(self.ns + "/initialized", b"1")
+        else:
+            self.cp0.get(self.ns + "/initialized", timeout_s=self.timeout_s)
         self.pull(model)
-        self.cp0.clock_set("workers", self.worker_index, 0)
+        if self.max_staleness is not None:
+            self.cp0.clock_set_wait("workers", self.worker_index, 0, None)
+
+    def close(self, grace_s: float = 20.0):
+        """End this worker's owner thread: wait for the chief's shutdown request to reach it, and if none comes
+        within ``grace_s`` (the chief is gone) queue one ourselves.  Idempotent; registered with ``atexit``."""
+        t, self._service_thread = self._service_thread, None
+        if t is not None and t.is_alive():
+            t.join(grace_s)
+            if t.is_alive():
+                try:
+                    self.cp0.push_json("%s/req/%d" % (self.ns, self.worker_index), {"op": "shutdown"})
+                except Exception:
+                    pass
+                t.join(10.0)
+        if self.region is not None and (t is None or not t.is_alive()):
+            self.region.close()
+            self.region = None
+
+    def _run_service(self):
+        try:
+            self._service.serve()
+        except BaseException:       # noqa: BLE001 - kept in service.error; the training thread raises it
+            pass
 
     def _stage(self, j: int, store, kind: str = "p") -> torch.Tensor:
         key = (j, kind)
@@ -486,65 +706,87 @@ class AsyncPSStrategy:
                                              device=store.device)
         return self._staging[key]
 
-    def _wait_counter(self, key: str, n: int):
-        t0 = time.time()
-        per_owner = not self.colocated
-        while True:
-            if per_owner:
-                tot = sum(self._cps[j].add(key, 0) for j in range(self.num_owners))
-            else:
-                tot = self.cp0.add(key, 0)
-            if tot >= n:
-                return
-            if time.time() - t0 > self.timeout_s:
-                raise TimeoutError("waiting for %s (%d/%d)" % (key, tot, n))
-            time.sleep(0.01)
+    def _init_owners(self, store, gs0: int):
+        """Chief: ship the initial values to every owner, reset their slots and the shared step."""
+        base = self.cp0.add(self.ns + "/init_done", 0)
+        if self.region is not None:
+            for j in range(self.num_owners):
+                b, e = self.ranges[j][0]
+                self.region.put(j, self.worker_index * self.slot_len, store.flat[b:e])
+            self.region.sync()
+            self._post("init", {"global_step": gs0})
+        else:
+            self._post("init", {"global_step": gs0})
+            sends = []
+            for j in range(self.num_owners):
+                n = _ranges_numel(self.ranges[j])
+                if n:
+                    sends.append((_pack(store.flat, self.ranges[j], self._stage(j, store, "g"))[:n].contiguous(),
+                                  self.owner_rank(j), _TAG_INIT))
+            self.p2p.exchange(sends, [])
+        self._wait_counter(self.ns + "/init_done", base + self.num_owners)
+        self.cp0.add("global_step", gs0 - self.cp0.add("global_step", 0))
+        self.last_global_step = gs0
 
     # -- data movement
-    def pull(self, model):
-        store = model.store
-        for j in range(self.num_owners):
-            self._cps[j].push_json("%s/%d" % (_REQ_QUEUE, j), {"op": "pull", "worker": self.worker_index})
-        for j in range(self.num_owners):
-            n = _ranges_numel(self.ranges[j])
-            if n:
-                buf = self._stage(j, store)[:n] if len(self.ranges[j]) > 1 else store.flat[self.ranges[j][0][0]:self.ranges[j][0][1]]
-                self.p2p.recv(buf, self.owner_rank(j), _TAG_PULL)
-                _unpack(buf, store.flat, self.ranges[j])
-            rep = self._reply(j)
-            self.versions[j] = rep["version"]
-
-    def _reply(self, j: int) -> dict:
-        key = "ps/reply/%d/%d" % (j, self.worker_index)
-        rep = self._cps[j].get_json(key, timeout_s=self.timeout_s)
-        self._cps[j].delete(key)
-        return rep
-
-    def apply_gradients(self, model):
-        """Push this step's gradients to every owner and pull the refreshed parameters back."""
-        store = model.store
-        if self.max_staleness is not None:
-            self.cp0.clock_wait("workers", self.clock, self.max_staleness, timeout_s=self.timeout_s)
-        for j in range(self.num_owners):
-            self._cps[j].push_json("%s/%d" % (_REQ_QUEUE, j), {"op": "pushpull", "worker": self.worker_index,
-                                                              "version": self.versions[j]})
-        sends, recvs, bufs = [], [], {}
+    def _receive_params(self, store):
+        """Parameters of every owner into ``store.flat`` (after the owners have been asked)."""
+        if self.region is not None:
+            reps = self._collect()           # owners reply after their put has completed
+            F = self.flat_len
+            store.flat.copy_(self.region.local[F:2 * F])
+            return reps
+        recvs, bufs = [], {}
         for j in range(self.num_owners):
             n = _ranges_numel(self.ranges[j])
             if not n:
                 continue
             single = len(self.ranges[j]) == 1
-            g = store.flat_grad[self.ranges[j][0][0]:self.ranges[j][0][1]] if single \
-                else _pack(store.flat_grad, self.ranges[j], self._stage(j, store, "g"))[:n]
             buf = store.flat[self.ranges[j][0][0]:self.ranges[j][0][1]] if single else self._stage(j, store, "p")[:n]
             bufs[j] = buf
-            sends.append((g, self.owner_rank(j), _TAG_PUSH))
             recvs.append((buf, self.owner_rank(j), _TAG_PULL))
-        self.p2p.exchange(sends, recvs)
-        for j in range(self.num_owners):
-            rep = self._reply(j)
-            if j in bufs:
-                _unpack(bufs[j], store.flat, self.ranges[j])
+        return recvs, bufs
+
+    def pull(self, model):
+        store = model.store
+        self._post("pull")
+        if self.region is not None:
+            reps = self._receive_params(store)
+        else:
+            recvs, bufs = self._receive_params(store)
+            self.p2p.exchange([], recvs)
+            for j, buf in bufs.items():
+                _unpack(buf, store.flat, self.ranges[j])
+            reps = self._collect()
+        for j, rep in enumerate(reps):
+            self.versions[j] = rep["version"]
+
+    def apply_gradients(self, model):
+        """Push this step's gradients to every owner and pull the refreshed parameters back."""
+        store = model.store
+        if self.region is not None:
+            for j in range(self.num_owners):
+                b, e = self.ranges[j][0]
+                self.region.put(j, self.worker_index * self.slot_len, store.flat_grad[b:e])
+            self.region.sync()                # gradients computed, copied and visible before the owners hear of them
+            self._post("pushpull", lambda j: {"version": self.versions[j]})
+            reps = self._receive_params(store)
+        else:
+            self._post("pushpull", lambda j: {"version": self.versions[j]})
+            sends = []
+            for j in range(self.num_owners):
+                n = _ranges_numel(self.ranges[j])
+                if not n:
+                    continue
+                g = store.flat_grad[self.ranges[j][0][0]:self.ranges[j][0][1]] if len(self.ranges[j]) == 1 \
+                    else _pack(store.flat_grad, self.ranges[j], self._stage(j, store, "g"))[:n]
+                sends.append((g, self.owner_rank(j), _TAG_PUSH))
+            recvs, bufs = self._receive_params(store)
+            self.p2p.exchange(sends, recvs)
+            for j, buf in bufs.items():
+                _unpack(buf, store.flat, self.ranges[j])
+            reps = self._collect()
+        for j, rep in enumerate(reps):
             self.versions[j] = rep["version"]
             self.staleness_hist[rep["staleness"]] = self.staleness_hist.get(rep["staleness"], 0) + 1
             if rep["global_step"] >= 0:
@@ -552,90 +794,71 @@ class AsyncPSStrategy:
         if self.last_global_step:
             store.global_step.fill_(self.last_global_step)
         self.clock += 1
-        self.cp0.clock_set("workers", self.worker_index, self.clock)
+        if self.max_staleness is not None:
+            # publish the new clock and wait for permission to start the next step, in one round trip
+            self.cp0.clock_set_wait("workers", self.worker_index, self.clock, self.max_staleness, timeout_s=self.timeout_s)
 
     def global_step(self) -> int:
         """Cluster-wide global step (one control-plane round trip)."""
-        return self.cp0.add("global_step", 0)
+        self.last_global_step = self.cp0.add("global_step", 0)
+        return self.last_global_step
+
+    def cached_global_step(self) -> int:
+        """The shared step as of this worker's last push (it travels back with owner 0's reply): what session hooks
+        read after every ``run``, without a round trip."""
+        return self.last_global_step
 
     def publish_state(self, model, is_chief: bool):
-        """Session creation: the chief (re-)initialises the owners from its store - e.g. right after it
-        restored a checkpoint - and the other workers wait for that, then everybody pulls."""
+        """Session creation: the chief (re-)initialises the owners - from the checkpoint it has just restored, slots
+        and ``beta*_power`` included, or else from its store - and the other workers wait for that, then everybody
+        pulls."""
         store = model.store
         first = not getattr(self, "_published", False)
         self._published = True
         if is_chief:
+            prefix = getattr(model, "_restored_from", None)
             gs = int(store.global_step.item())
-            base = self._counter_total("ps/init_done")
-            for j in range(self.num_owners):
-                self._cps[j].push_json("%s/%d" % (_REQ_QUEUE, j), {"op": "init", "worker": self.worker_index,
-                                                                  "global_step": gs})
-                n = _ranges_numel(self.ranges[j])
-                if n:
-                    self.p2p.send(_pack(store.flat, self.ranges[j], self._stage(j, store, "g"))[:n].contiguous(),
-                                  self.owner_rank(j), _TAG_INIT)
-            self._wait_counter("ps/init_done", base + self.num_owners)
-            self.cp0.add("global_step", gs - self.cp0.add("global_step", 0))
+            if prefix:
+                model._restored_from = None
+                self.restore(model, prefix, uuid.uuid4().hex)
+                self.cp0.add("global_step", gs - self.cp0.add("global_step", 0))
+                self.last_global_step = gs
+            else:
+                self._init_owners(store, gs)
         if first:
-            self.cp0.barrier("ps/publish", self.num_workers, timeout_s=self.timeout_s)
+            self.cp0.barrier(self.ns + "/publish", self.num_workers, timeout_s=self.timeout_s)
         self.pull(model)
         store.global_step.fill_(self.global_step())
-
-    def _counter_total(self, key: str) -> int:
-        if self.colocated:
-            return self.cp0.add(key, 0)
-        return sum(self._cps[j].add(key, 0) for j in range(self.num_owners))
 
     def reduce_stats(self, stats):
         return stats
 
     # -- checkpoints: each owner writes its own data shard, the chief merges the index
-    def _tensor_table(self, store):
-        table = {str(j): [] for j in range(self.num_owners)}
-        shapes = {}
-        if self.placement_name == "flat":
-            return None, None
-        tr = store.trainable
-        for j in range(self.num_owners):
-            off = 0
-            for b, e in self.ranges[j]:
-                for i, v in enumerate(tr):
-                    end = tr[i + 1].offset if i + 1 < len(tr) else store.flat_len
-                    if v.offset >= b and end <= e:
-                        table[str(j)].append((v.name, v.offset, end, off + (v.offset - b)))
-                        shapes[v.name] = list(v.shape)
-                off += e - b
-        return table, shapes
-
     def save(self, model, prefix: str, token: str):
-        table, shapes = self._tensor_table(model.store)
-        if table is None:
-            raise NotImplementedError("flat-sharded owners checkpoint through the worker-side Saver after a pull")
         slots = getattr(model.optimizer, "slot_checkpoint_names", {})
         gs = self.global_step()
-        for j in range(self.num_owners):
-            self._cps[j].push_json("%s/%d" % (_REQ_QUEUE, j), {
-                "op": "save", "prefix": prefix, "num_shards": self.num_owners, "tensors": table, "shapes": shapes,
-                "slots": slots, "global_step": gs, "optimizer": model.optimizer.name, "token": token})
-        self._wait_counter("ps/save_done/%s" % token, self.num_owners)
+        base = self.cp0.add("%s/save_done/%s" % (self.ns, token), 0)
+        self._post("save", {"prefix": prefix, "num_shards": self.num_owners, "slots": slots, "global_step": gs,
+                            "optimizer": model.optimizer.name, "token": token, "gather": self.gather})
+        self._wait_counter("%s/save_done/%s" % (self.ns, token), base + self.num_owners)
+        self._check_service()
         from ..saver import merge_shards
         merge_shards(prefix, self.num_owners)
         return prefix
 
     def restore(self, model, prefix: str, token: str):
-        table, shapes = self._tensor_table(model.store)
+        """Owners reload variables, optimizer slots, ``beta*_power`` and the step from the checkpoint files."""
         slots = getattr(model.optimizer, "slot_checkpoint_names", {})
-        for j in range(self.num_owners):
-            self._cps[j].push_json("%s/%d" % (_REQ_QUEUE, j), {
-                "op": "restore", "prefix": prefix, "tensors": table, "shapes": shapes, "slots": slots, "token": token})
-        self._wait_counter("ps/restore_done/%s" % token, self.num_owners)
+        self._post("restore", {"prefix": prefix, "slots": slots, "token": token})
+        self._wait_counter("%s/restore_done/%s" % (self.ns, token), self.num_owners)
+        self._check_service()
 
     def owner_stats(self) -> List[dict]:
         out = []
         for j in range(self.num_owners):
-            self._cps[j].delete("ps/stats/%d" % j)
-            self._cps[j].push_json("%s/%d" % (_REQ_QUEUE, j), {"op": "stats"})
-            out.append(self._cps[j].get_json("ps/stats/%d" % j, timeout_s=self.timeout_s))
+            self._cps[j].delete("%s/stats/%d" % (self.ns, j))
+            self._cps[j].push_json("%s/req/%d" % (self.ns, j), {"op": "stats"})
+            out.append(self._cps[j].get_json("%s/stats/%d" % (self.ns, j), timeout_s=self.timeout_s))
         return out
 
     def worker_done(self):
@@ -644,11 +867,15 @@ class AsyncPSStrategy:
         self.cp0.clock_set("workers", self.worker_index, 1 << 60)   # a finished worker never holds others back
 
     def shutdown_owners(self, wait_for_workers: bool = True):
-        """Chief only: ends ``server.join()`` in every ps task (the reference has no such protocol).
-        Waits until every worker has reported ``worker_done`` so nobody is cut off mid-step."""
+        """Chief only: ends ``server.join()`` in every ps task and every colocated owner thread (the reference has
+        no such protocol).  Waits until every worker has reported ``worker_done`` so nobody is cut off mid-step."""
         if wait_for_workers:
-            t0 = time.time()
-            while self.cp0.add("workers_done", 0) < self.num_workers and time.time() - t0 < self.timeout_s:
-                time.sleep(0.02)
+            try:
+                self.cp0.wait_counter("workers_done", self.num_workers, timeout_s=self.timeout_s)
+            except ControlTimeout:
+                pass
         for j in range(self.num_owners):
-            self._cps[j].push_json("%s/%d" % (_REQ_QUEUE, j), {"op": "shutdown"})
+            self._cps[j].push_json("%s/req/%d" % (self.ns, j), {"op": "shutdown"})
+        if self.colocated and self.server.num_ps > 0:
+            # ps tasks that only served the control plane leave join() too
+            self.server.shutdown_parameter_servers()

@@ -1,0 +1,195 @@
+"""Peer-mapped memory regions: one-sided ``put`` / ``get`` between the ranks of one node.
+
+The data plane of the asynchronous parameter-server mode when owners live inside the worker processes (8 workers on
+8 GPUs, variables sharded over all eight HBMs).  Each rank allocates one region, publishes a handle through the
+control plane and maps everybody else's region:
+
+* on GPUs the region is device memory shared through hipIpc (``csrc/kernels/peer_mailbox.hip``); a ``put`` is one
+  device-to-device copy over xGMI on the caller's current stream and ``sync()`` waits for that stream;
+* on CPUs (tests, the reference's "localhost plumbing" configuration) it is a POSIX shared-memory segment and a
+  ``put`` is a memcpy.
+
+Either way a message needs no rendezvous with the receiving process - the sender writes, synchronises, and then tells
+the receiver over the control plane - which is what lets owners serve workers in arrival order without any of the
+ordering hazards of two threads sharing a send/recv communicator.  The reference moves the same tensors through
+gRPC ``RecvTensor`` (/root/reference/example.py:128-129).
+"""
+from __future__ import annotations
+
+import base64
+import ctypes as C
+import os
+import uuid
+from typing import List, Optional
+
+import torch
+
+from ..ops import _native as nv
+
+_lib = None
+
+
+def _k():
+    global _lib
+    if _lib is None:
+        lib = nv.kernels()
+        p, ll = C.c_void_p, C.c_longlong
+        nv.declare(lib, "dtf_mbox_create", [C.c_int, C.c_int, ll], p)
+        nv.declare(lib, "dtf_mbox_handle_bytes", [])
+        nv.declare(lib, "dtf_mbox_bytes", [p], ll)
+        nv.declare(lib, "dtf_mbox_local_ptr", [p], p)
+        nv.declare(lib, "dtf_mbox_local_handle", [p, p])
+        nv.declare(lib, "dtf_mbox_open_peer", [p, C.c_int, p])
+        nv.declare(lib, "dtf_mbox_put", [p, C.c_int, ll, p, ll, p])
+        nv.declare(lib, "dtf_mbox_get", [p, C.c_int, ll, p, ll, p])
+        nv.declare(lib, "dtf_mbox_sync", [p])
+        nv.declare(lib, "dtf_mbox_destroy", [p], None)
+        _lib = lib
+    return _lib
+
+
+class _DeviceMemory:
+    """Lets ``torch.as_tensor`` alias raw device memory (the CUDA array interface)."""
+
+    def __init__(self, ptr: int, nfloats: int):
+        self.__cuda_array_interface__ = {"shape": (int(nfloats),), "typestr": "<f4", "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+class PeerRegion:
+    """``nfloats`` float32 of memory per rank, every rank's region addressable from every rank.
+
+    Construction is collective over the ``world`` ranks that share ``name`` on the control plane ``cp`` (handles are
+    exchanged through its key/value store; nobody returns before all regions are mapped).
+    """
+
+    def __init__(self, rank: int, world: int, nfloats: int, device, cp, name: str = "mbox", timeout_s: float = 300.0):
+        self.rank, self.world, self.nfloats = int(rank), int(world), int(nfloats)
+        self.device = torch.device(device)
+        self.name = name
+        self._h = None
+        self._shm = None
+        self._peers_shm: List = []
+        self._peer_views: List[Optional[torch.Tensor]] = [None] * self.world
+        if self.device.type == "cuda":
+            self._init_gpu(cp, timeout_s)
+        else:
+            self._init_cpu(cp, timeout_s)
+        cp.barrier("%s/mapped" % name, self.world, timeout_s=timeout_s)
+
+    # ------------------------------------------------------------------ GPU: hipIpc
+    def _init_gpu(self, cp, timeout_s):
+        lib = _k()
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        with torch.cuda.device(self.device):
+            self._h = lib.dtf_mbox_create(self.rank, self.world, self.nfloats * 4)
+            if not self._h:
+                raise RuntimeError("cannot allocate a %d-float peer region on %s" % (self.nfloats, self.device))
+            nb = lib.dtf_mbox_handle_bytes()
+            mine = C.create_string_buffer(nb)
+            rc = lib.dtf_mbox_local_handle(self._h, mine)
+            if rc:
+                raise RuntimeError("hipIpcGetMemHandle failed (%d)" % rc)
+            cp.set("%s/handle/%d" % (self.name, self.rank), base64.b64encode(bytes(mine.raw)))
+            for r in range(self.world):
+                if r == self.rank:
+                    continue
+                raw = base64.b64decode(cp.get("%s/handle/%d" % (self.name, r), timeout_s=timeout_s))
+                rc = lib.dtf_mbox_open_peer(self._h, r, C.create_string_buffer(raw, nb))
+                if rc:
+                    raise RuntimeError("hipIpcOpenMemHandle of rank %d's region failed (%d)" % (r, rc))
+            self.local = torch.as_tensor(_DeviceMemory(lib.dtf_mbox_local_ptr(self._h), self.nfloats), device=self.device)
+
+    # ------------------------------------------------------------------ CPU: POSIX shared memory
+    def _init_cpu(self, cp, timeout_s):
+        from multiprocessing import resource_tracker, shared_memory
+        seg = "dtf_%s_%d" % (uuid.uuid4().hex[:12], self.rank)
+        self._shm = shared_memory.SharedMemory(name=seg, create=True, size=max(self.nfloats * 4, 4))
+        self.local = torch.frombuffer(self._shm.buf, dtype=torch.float32, count=self.nfloats)
+        self.local.zero_()
+        cp.set("%s/handle/%d" % (self.name, self.rank), seg.encode())
+        self._peer_views[self.rank] = self.local
+        for r in range(self.world):
+            if r == self.rank:
+                continue
+            peer_name = cp.get("%s/handle/%d" % (self.name, r), timeout_s=timeout_s).decode()
+            shm = shared_memory.SharedMemory(name=peer_name)
+            try:        # the attaching process must not unlink the creator's segment when it exits
+                resource_tracker.unregister(shm._name, "shared_memory")
+            except Exception:
+                pass
+            self._peers_shm.append(shm)
+            self._peer_views[r] = torch.frombuffer(shm.buf, dtype=torch.float32, count=self.nfloats)
+
+    # ------------------------------------------------------------------ data movement
+    def _check(self, t: torch.Tensor, off: int):
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise ValueError("peer regions move contiguous float32 tensors")
+        if off < 0 or off + t.numel() > self.nfloats:
+            raise ValueError("range [%d, %d) outside the %d-float region" % (off, off + t.numel(), self.nfloats))
+
+    def put(self, peer: int, dst_off: int, src: torch.Tensor):
+        """``region[peer][dst_off : dst_off + src.numel()] = src`` (GPU: asynchronously, on the current stream)."""
+        self._check(src, dst_off)
+        if src.numel() == 0:
+            return
+        if self._h is not None:
+            rc = _k().dtf_mbox_put(self._h, int(peer), int(dst_off) * 4, src.data_ptr(), src.numel() * 4,
+                                   torch.cuda.current_stream(self.device).cuda_stream)
+            if rc:
+                raise RuntimeError("peer put to rank %d failed (%d)" % (peer, rc))
+        else:
+            self._peer_views[peer][dst_off:dst_off + src.numel()].copy_(src.reshape(-1))
+
+    def get(self, peer: int, src_off: int, dst: torch.Tensor):
+        """``dst = region[peer][src_off : src_off + dst.numel()]``."""
+        self._check(dst, src_off)
+        if dst.numel() == 0:
+            return
+        if self._h is not None:
+            rc = _k().dtf_mbox_get(self._h, int(peer), int(src_off) * 4, dst.data_ptr(), dst.numel() * 4,
+                                   torch.cuda.current_stream(self.device).cuda_stream)
+            if rc:
+                raise RuntimeError("peer get from rank %d failed (%d)" % (peer, rc))
+        else:
+            dst.reshape(-1).copy_(self._peer_views[peer][src_off:src_off + dst.numel()])
+
+    def sync(self):
+        """Wait until every put / get issued on the current stream has completed (and is visible to its target)."""
+        if self._h is not None:
+            rc = _k().dtf_mbox_sync(torch.cuda.current_stream(self.device).cuda_stream)
+            if rc:
+                raise RuntimeError("stream synchronisation failed (%d)" % rc)
+
+    def close(self):
+        h, self._h = self._h, None
+        if h:
+            self.local = None
+            with torch.cuda.device(self.device):
+                _k().dtf_mbox_destroy(h)
+        if self._shm is not None or self._peers_shm:
+            # tensors made by frombuffer pin the mappings: drop them before closing
+            self.local = None
+            self._peer_views = [None] * self.world
+            for shm in self._peers_shm:
+                try:
+                    shm.close()
+                except Exception:
+                    pass
+            self._peers_shm = []
+            if self._shm is not None:
+                try:
+                    self._shm.close()
+                except Exception:
+                    pass
+                try:
+                    self._shm.unlink()
+                except Exception:
+                    pass
+                self._shm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -79,7 +79,7 @@ def test_resume_restores_variables_slots_and_step(tmp_path):
     with ss.MonitoredTrainingSession(engine=eng2, checkpoint_dir=d, hooks=[ss.StopAtStepHook(last_step=20)]) as sess:
         assert sess.global_step_value() == 20 and sess.should_stop()     # budget already spent: nothing runs
         assert torch.equal(m2.store.flat, flat) and torch.equal(m2.store.slot("m"), mslot)
-        assert abs(m2.store.beta_powers[0].item() - 0.9 ** 20) < 1e-6
+        assert abs(m2.store.beta_powers[0].item() - 0.9 ** 21) < 1e-6     # TF convention: beta^(t+1) after t updates
 
 
 def test_recoverable_error_restores_last_checkpoint_and_retries(tmp_path):

@@ -1,4 +1,5 @@
-"""Sync-replica strategy on CPU: world_size 2 over gloo must match a single process fed the union batch."""
+"""Sync-replica strategy on CPU: world sizes 2 and 8 over gloo must match a single process fed the union batch
+(the 64*world alignment of the flat buffer and the bucket split are the same arithmetic an 8-GPU node runs)."""
 import os
 import socket
 import sys
@@ -42,10 +43,10 @@ def _worker(rank, world, port, bucket_bytes, allreduce_below, out_q):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("world", [2, 8])
 @pytest.mark.parametrize("bucket_bytes,allreduce_below", [(64 << 20, 0), (4096, 0), (64 << 20, 8 << 20)],
                          ids=["one_bucket", "many_buckets", "replicated_allreduce"])
-def test_sync_replicas_matches_single_process(bucket_bytes, allreduce_below):
-    world = 2
+def test_sync_replicas_matches_single_process(bucket_bytes, allreduce_below, world):
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -57,8 +58,8 @@ def test_sync_replicas_matches_single_process(bucket_bytes, allreduce_below):
         p.join(timeout=60)
         assert p.exitcode == 0
     # replicas agree bit for bit and advanced global_step once per aggregated update
-    assert torch.equal(res[0][1], res[1][1])
-    assert res[0][2] == 5 and res[1][2] == 5
+    assert all(torch.equal(res[0][1], r[1]) for r in res[1:])
+    assert all(r[2] == 5 for r in res)
     if bucket_bytes == 4096:
         assert res[0][4] > 1
     assert res[0][5] == (allreduce_below > 0) and (not res[0][5] or res[0][4] == 0)
