@@ -528,7 +528,10 @@ class AsyncPSStrategy:
         self.worker_index = server.task_index
         self.num_workers = server.num_workers
         if colocated is None:
-            colocated = server.num_ps == 0 or not server.ps_tasks_have_devices()
+            import os
+            forced = os.environ.get("DTF_COLOCATED_OWNERS")      # "1" / "0": override the device-driven choice
+            colocated = (forced == "1") if forced in ("0", "1") and server.num_ps > 0 else \
+                (server.num_ps == 0 or not server.ps_tasks_have_devices())
         self.colocated = bool(colocated)
         self.num_owners = self.num_workers if self.colocated else server.num_ps
         if placement == "flat" and not self.colocated:
