@@ -229,7 +229,7 @@ def run_rank(args) -> None:
         else:
             init_process_group(backend, device=dev if on_gpu else None)
         strategy = SyncReplicasStrategy(Communicator(), bucket_bytes=int(args.bucket_mb * (1 << 20)))
-    data_plane = dist.get_backend() if dist.is_initialized() else None
+    data_plane = dist.get_backend() if dist.is_initialized() else None      # what barriers / timing reductions use
 
     B = args.batch_per_gpu or DEFAULT_BATCH[args.model]
     metrics = ["accuracy"]
@@ -368,9 +368,11 @@ def run_rank(args) -> None:
     # a slice of (the statistics are summed over ranks)
     test_acc = None
     n_eval = args.eval if args.eval >= 0 else (5 if args.model == "wide_mlp" else 100)
-    if n_eval > 0 and args.mode == "sync":
+    if n_eval > 0:
         run(done, n_eval)
         done += n_eval
+        if args.mode == "async":
+            strategy.pull(model)         # the owners' current variables (no collective: every worker evaluates alone)
         n_test = 8192
         xt, yt = make(n_test * world, 99)
         res = model.evaluate(xt[rank * n_test:(rank + 1) * n_test], yt[rank * n_test:(rank + 1) * n_test],
@@ -428,7 +430,9 @@ def run_rank(args) -> None:
                        "train_loss": logs.get("loss"), "train_acc": logs.get("acc"), "test_acc": test_acc,
                        "eval_steps": n_eval if test_acc is not None else 0,
                        "steady_warmup_steps": steady_windows * 10,
-                       "data_plane": {"nccl": "rccl"}.get(data_plane, data_plane), "rccl_ranks": group_size,
+                       "data_plane": ("peer regions (%s), control plane over TCP" % ("hipIpc over xGMI" if on_gpu else "shared memory")
+                                      if args.mode == "async" else {"nccl": "rccl"}.get(data_plane, data_plane)),
+                       "rccl_ranks": group_size,
                        "self_launched": os.environ.get("DTF_BENCH_SELF_LAUNCHED") == "1",
                        "ranks": ranks,
                        **({"device": "cpu (plumbing rehearsal, not a benchmark)"} if not on_gpu else {}),

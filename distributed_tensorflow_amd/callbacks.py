@@ -273,6 +273,23 @@ class LambdaCallback(Callback):
             self._te(logs)
 
 
+class ClusterHealth(Callback):
+    """Inside a cluster session ``model.fit`` never passes through ``session.run``, so the session's heartbeat hook
+    gets no chance to report a lost task; this callback asks the session at every epoch boundary instead and lets the
+    resulting ``ClusterLostError`` end ``fit``.  (A worker that is stuck mid-epoch in a transfer with the dead task is
+    ended by the failure detector itself.)"""
+
+    def __init__(self, session):
+        super().__init__()
+        self.session = session
+
+    def on_epoch_begin(self, epoch, logs=None):
+        self.session.check_health()
+
+    def on_epoch_end(self, epoch, logs=None):
+        self.session.check_health()
+
+
 class CallbackList:
     def __init__(self, callbacks: Optional[List[Callback]], model, params):
         self.callbacks = list(callbacks or [])

@@ -313,7 +313,16 @@ class GraphEngine(ModelEngine):
                 host, port = srv.rendezvous_address()
                 init_process_group(None, rank=srv.task_index, world_size=srv.num_workers, master_addr=host,
                                    master_port=port)
-            return SyncReplicasStrategy(Communicator())
+            comm = Communicator()
+            # every step aggregates exactly one gradient from every replica (a collective has no "first N of M" mode
+            # and no stale gradients to drop): any other request cannot be honoured, so it is refused, not ignored
+            for what, n in (("replicas_to_aggregate", opt_node.replicas_to_aggregate),
+                            ("total_num_replicas", opt_node.total_num_replicas)):
+                if n is not None and int(n) != comm.world_size:
+                    raise ValueError("SyncReplicasOptimizer(%s=%d) but the cluster has %d workers: synchronous replicas "
+                                     "here always aggregate one gradient per worker (leave it unset or pass %d)"
+                                     % (what, int(n), comm.world_size, comm.world_size))
+            return SyncReplicasStrategy(comm)
         if srv is not None and setter is not None and setter.cluster is not None:
             from .parallel.async_ps import AsyncPSStrategy
             return AsyncPSStrategy(srv, max_staleness=self.graph.__dict__.get("max_staleness"),
@@ -481,6 +490,7 @@ class SyncReplicasOptimizer(_GraphOptimizer):
                  total_num_replicas: Optional[int] = None, name="sync_replicas"):
         super().__init__(opt.optimizer)
         self.replicas_to_aggregate = replicas_to_aggregate
+        self.total_num_replicas = total_num_replicas
 
     def make_session_run_hook(self, is_chief, num_tokens=-1):
         return _session.SessionRunHook()

@@ -41,6 +41,16 @@ class OutOfRangeError(RuntimeError):
 RECOVERABLE_ERRORS = (AbortedError, UnavailableError)
 
 
+def _transient_errors():
+    """Real faults that are worth one in-process recovery: a control-plane request that timed out (an owner was slow
+    to answer, a connection hiccup).  They are treated like TF's ``UnavailableError``: the session re-creates itself
+    from the last checkpoint and retries; if the peer is really gone the recovery itself fails - or the failure
+    detector reports ``ClusterLostError``, which is never retried in process (a static process group cannot re-admit
+    a member: the launcher restarts the gang)."""
+    from .control import ControlTimeout
+    return (ControlTimeout,)
+
+
 # --------------------------------------------------------------------------- hook protocol
 class SessionRunArgs:
     def __init__(self, fetches=None, feed_dict=None):
@@ -360,7 +370,7 @@ class MonitoredSession:
         while True:
             try:
                 return self._run_once(fetches, feed_dict)
-            except RECOVERABLE_ERRORS as e:
+            except RECOVERABLE_ERRORS + _transient_errors() as e:
                 self._recoveries += 1
                 if self._recoveries > self.max_recoveries:
                     raise
@@ -385,6 +395,14 @@ class MonitoredSession:
         if ctx.stop_requested:
             self._stop = True
         return results["caller"]
+
+    def check_health(self):
+        """Raise ``ClusterLostError`` if the failure detector of this session has lost a task (for loops that do not
+        go through ``run``, such as ``model.fit`` inside a session)."""
+        for h in self.hooks:
+            d = getattr(h, "detector", None)
+            if d is not None:
+                d.check()
 
     def close(self, run_end_hooks: bool = True):
         if self._closed:

@@ -16,7 +16,7 @@ from time import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from distributed_tensorflow_amd import compat as tf                        # noqa: E402
-from distributed_tensorflow_amd.callbacks import TensorBoard              # noqa: E402
+from distributed_tensorflow_amd.callbacks import ClusterHealth, TensorBoard  # noqa: E402
 from distributed_tensorflow_amd.data import get_data                       # noqa: E402
 from distributed_tensorflow_amd.engine import ModelEngine                  # noqa: E402
 from distributed_tensorflow_amd.layers import Dense, Dropout              # noqa: E402
@@ -46,10 +46,11 @@ FLAGS = flags.FLAGS
 
 
 def make_strategy():
-    """None on a single machine; otherwise the strategy of this worker task (a ps task serves and exits)."""
+    """(strategy, session target): (None, "") on a single machine; otherwise the strategy of this worker task and its
+    server's target (a ps task serves and exits)."""
     if FLAGS.job_name is None:
         print("Running single-machine training")
-        return None
+        return None, ""
     print("Running distributed training")
     cluster = tf.train.ClusterSpec({"ps": FLAGS.ps_hosts.split(","), "worker": FLAGS.worker_hosts.split(",")})
     server = tf.train.Server(cluster, job_name=FLAGS.job_name, task_index=FLAGS.task_index)
@@ -58,15 +59,15 @@ def make_strategy():
         sys.exit(0)
     if FLAGS.mode == "async":
         from distributed_tensorflow_amd.parallel.async_ps import AsyncPSStrategy
-        return AsyncPSStrategy(server)
+        return AsyncPSStrategy(server), server.target
     from distributed_tensorflow_amd.parallel import Communicator, SyncReplicasStrategy, init_process_group
     host, port = server.rendezvous_address()
     init_process_group(None, rank=server.task_index, world_size=server.num_workers, master_addr=host, master_port=port)
-    return SyncReplicasStrategy(Communicator())
+    return SyncReplicasStrategy(Communicator()), server.target
 
 
 def main():
-    strategy = make_strategy()
+    strategy, target = make_strategy()
     seed = None if FLAGS.seed < 0 else FLAGS.seed
 
     model = Sequential()
@@ -85,8 +86,12 @@ def main():
                                               device=model.device)
 
     is_chief = FLAGS.task_index == 0
-    with MonitoredTrainingSession(master="", is_chief=is_chief, engine=ModelEngine(model)):
+    # master=target: in a cluster the session then watches the other tasks' heartbeats, so a lost peer surfaces as
+    # ClusterLostError instead of a hang (/root/reference/example2.py:189-190 passes master=target as well)
+    with MonitoredTrainingSession(master=target, is_chief=is_chief, engine=ModelEngine(model)) as sess:
         callbacks = [TensorBoard(log_dir=FLAGS.log_dir.format(time()))] if is_chief else []
+        if FLAGS.job_name is not None:
+            callbacks.append(ClusterHealth(sess))
         history = model.fit(x_train, y_train, epochs=FLAGS.epochs, batch_size=FLAGS.batch_size,
                             validation_data=(x_val, y_val), callbacks=callbacks, verbose=1 if is_chief else 0,
                             steps_per_graph=FLAGS.steps_per_graph)

@@ -115,3 +115,40 @@ def test_gang_restart_after_a_task_is_killed(tmp_path, victim):
     assert last_step <= step <= last_step + 4          # continued to the absolute step budget, not a fresh run
     with BundleReader(ck) as r:
         assert step <= int(r.get_tensor("global_step").item()) <= step + 1
+
+
+def test_example2_cluster_surfaces_a_lost_worker(tmp_path):
+    """The Keras-style script in a cluster: it opens its session with ``master=server.target``, so heartbeats run, and a
+    killed worker ends the survivor with ClusterLostError (from the epoch-boundary health check) or through the failure
+    detector's abort (status 75) - never a hang."""
+    from .test_example_cluster import _ports
+    script = os.path.join(ROOT, "examples", "example2.py")
+    ps_port, w0, w1, rdv = _ports(4)
+    hosts = {"PS_HOSTS": "127.0.0.1:%d" % ps_port, "WORKER_HOSTS": "127.0.0.1:%d,127.0.0.1:%d" % (w0, w1),
+             "DTF_RENDEZVOUS_PORT": str(rdv), "DTF_HEARTBEAT_MAX_AGE_SECS": "1.5", "DTF_HEARTBEAT_ABORT_SECS": "3",
+             "DTF_HEARTBEAT_SECS": "0.2"}
+    args = [sys.executable, script, "--log_dir", str(tmp_path / "logs"), "--epochs", "100000", "--mode", "async", "--seed", "1"]
+    procs, logs = {}, {}
+    try:
+        for job, idx in (("ps", 0), ("worker", 0), ("worker", 1)):
+            logs[(job, idx)] = open(str(tmp_path / ("%s%d.log" % (job, idx))), "w+")
+            procs[(job, idx)] = subprocess.Popen(args, env=_env(dict(hosts, JOB_NAME=job, TASK_INDEX=str(idx))),
+                                                 stdout=logs[(job, idx)], stderr=subprocess.STDOUT)
+
+        def training():
+            logs[("worker", 0)].flush()
+            logs[("worker", 0)].seek(0)
+            return "Epoch 3/" in logs[("worker", 0)].read()
+        assert _wait(training, timeout=120), "worker 0 never started training"
+        procs[("worker", 1)].kill()
+        rc = procs[("worker", 0)].wait(timeout=60)
+        logs[("worker", 0)].seek(0)
+        text = logs[("worker", 0)].read()
+        assert rc != 0
+        assert "ClusterLostError" in text or rc == 75, text[-2000:]
+    finally:
+        for p in procs.values():
+            if p.poll() is None:
+                p.kill()
+        for f in logs.values():
+            f.close()

@@ -116,3 +116,57 @@ def test_logging_and_nan_hooks():
     with pytest.raises(FloatingPointError):
         with ss.MonitoredSession(eng, hooks=[ss.NanLossHook(LOSS)]) as sess:
             loop(sess, 1)
+
+
+def test_control_plane_timeout_is_recovered_like_unavailable(tmp_path):
+    """A real transient fault - a control-plane request that timed out inside the engine - takes the same path as TF's
+    UnavailableError: restore the last checkpoint, retry the run."""
+    from distributed_tensorflow_amd.control import ControlTimeout
+    d = str(tmp_path)
+    m, eng = make()
+    real_run, fired = eng.run, []
+
+    def flaky(fetches, feed_dict=None):
+        if m._host_step == 7 and not fired:
+            fired.append(1)
+            raise ControlTimeout("take_many co/reply/0/0 timed out")
+        return real_run(fetches, feed_dict)
+
+    eng.run = flaky
+    hooks = [ss.CheckpointSaverHook(d, save_secs=None, save_steps=5), ss.StopAtStepHook(last_step=12)]
+    with ss.MonitoredSession(eng, checkpoint_dir=d, hooks=hooks, recovery_wait_secs=0.0) as sess:
+        loop(sess)
+        assert fired and sess._recoveries == 1
+        assert sess.global_step_value() == 12
+
+
+def test_hooks_share_one_step_read_per_run_and_no_device_sync(tmp_path, monkeypatch):
+    """A ``run`` that fetches nothing from the device costs no device->host read: every hook shares ONE read of the
+    engine's host-side step counter (StopAtStep, StepCounter, SummarySaver, CheckpointSaver all ask).  Reads made by
+    the CPU reference kernels (``ops/functional.py`` takes the step from the tensor; the HIP kernels read it on the
+    device) are not the session's."""
+    import traceback
+    m, eng = make()
+    reads = []
+    real_item, real_tolist = torch.Tensor.item, torch.Tensor.tolist
+
+    def note(real):
+        def wrapped(self):
+            caller = traceback.extract_stack()[-2].filename
+            if not caller.endswith(os.path.join("ops", "functional.py")):
+                reads.append(caller)
+            return real(self)
+        return wrapped
+
+    monkeypatch.setattr(torch.Tensor, "item", note(real_item))
+    monkeypatch.setattr(torch.Tensor, "tolist", note(real_tolist))
+    with ss.MonitoredTrainingSession(engine=eng, checkpoint_dir=str(tmp_path), save_summaries_steps=None,
+                                     hooks=[ss.StopAtStepHook(last_step=40)]) as sess:
+        x, y = DATA[0][:50], DATA[1][:50]
+        sess.run(TRAIN_OP, {"x": x, "y": y})               # first step: the checkpoint hook saves (reads allowed)
+        del reads[:]
+        s0 = sess.step_reads
+        for _ in range(20):
+            sess.run(TRAIN_OP, {"x": x, "y": y})
+        assert sess.step_reads - s0 == 20                   # one shared read per run ...
+        assert reads == []                                  # ... served from the host mirror: no tensor was read back
