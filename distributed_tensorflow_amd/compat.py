@@ -130,6 +130,15 @@ class Graph:
     def get_config(self):
         return self.as_graph_def()
 
+    def graph_def_nodes(self):
+        """GraphDef nodes: those of the lowered model (variables on the devices the device setter chose, layer ops,
+        loss, optimizer) once the graph has an engine, the symbolic nodes as written before that."""
+        from . import graph_def as gd
+        if self._engine is not None and self._engine.model is not None:
+            return self._engine.graph_def_nodes()
+        return [gd.Node(n.name, n.op if n.op != "layer" else type(n.attrs["layer"]).__name__,
+                        [i.name for i in n.inputs if isinstance(i, Tensor)], n.device) for n in self.nodes]
+
     def engine(self) -> "GraphEngine":
         if self._engine is None:
             self._engine = GraphEngine(self)
@@ -368,6 +377,21 @@ class GraphEngine(ModelEngine):
     def describe(self) -> str:
         import json
         return json.dumps(self.graph.as_graph_def(), indent=1)
+
+    def graph_def_nodes(self):
+        from . import graph_def as gd
+        srv = _cluster.current_server()
+        wdev = "/job:worker/task:%d" % srv.task_index if srv is not None and srv.job_name == "worker" else ""
+        setter = self.graph.device_setter
+
+        def vdev(name: str) -> str:
+            if setter is not None and setter.ps_tasks > 0:
+                return setter("Variable", name=name)          # round-robin in creation order, like TF
+            return wdev
+        return gd.model_nodes(self.model, worker_device=wdev, variable_device=vdev,
+                              loss_name=getattr(self.model.loss, "name", None),
+                              optimizer_name=getattr(self.model.optimizer, "name", None),
+                              input_name=self.input.name, labels_name=self.labels.name)
 
     def variable_value(self, node):
         if node is self.global_step_node or node.name.endswith("global_step"):

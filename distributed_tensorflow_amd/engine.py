@@ -52,6 +52,29 @@ class ModelEngine:
     def describe(self) -> str:
         return json.dumps(self.model.get_config(), indent=1, default=str)
 
+    def variable_device_fn(self, worker_device: str = ""):
+        """name -> device string of a variable under the model's strategy (``/job:ps/task:k`` for whole variables
+        owned by ps task k; the worker's own device otherwise)."""
+        placement = getattr(self.model.strategy, "placement", None) or {}
+        colocated = bool(getattr(self.model.strategy, "colocated", False))
+
+        def dev(name: str) -> str:
+            k = placement.get(name, placement.get(name.rsplit("/", 1)[0]))
+            if k is None or k < 0 or colocated:
+                return worker_device
+            return "/job:ps/task:%d" % k
+        return dev
+
+    def graph_def_nodes(self):
+        """GraphDef nodes of the compiled model (for ``FileWriter.add_graph`` and ``graph.pbtxt``)."""
+        from . import graph_def as gd
+        from .cluster import current_server
+        srv = current_server()
+        wdev = "/job:worker/task:%d" % srv.task_index if srv is not None and srv.job_name == "worker" else ""
+        return gd.model_nodes(self.model, worker_device=wdev, variable_device=self.variable_device_fn(wdev),
+                              loss_name=getattr(self.model.loss, "name", None),
+                              optimizer_name=getattr(self.model.optimizer, "name", None))
+
     # ---- global step
     def global_step_value(self) -> int:
         """The (cluster-wide) step counter without a device synchronisation: single-replica and synchronous-replica

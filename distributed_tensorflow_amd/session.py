@@ -186,10 +186,11 @@ class CheckpointSaverHook(SessionRunHook):
 
     def after_create_session(self, session, coord):
         os.makedirs(self.dir, exist_ok=True)
-        # TF writes graph.pbtxt here; we write a readable description of the model next to the checkpoints
+        # like TF's CheckpointSaverHook: the GraphDef in text format next to the checkpoints
         try:
+            from . import graph_def as gd
             with open(os.path.join(self.dir, "graph.pbtxt"), "w") as f:
-                f.write("# model description (not a TensorFlow GraphDef)\n%s\n" % session.describe_graph())
+                f.write(gd.graph_def_text(gd.nodes_for(session.graph)))
         except OSError:
             pass
 

@@ -162,16 +162,12 @@ class FileWriter:
         self.add_summary(Summary([(tag, value)]), global_step)
 
     def add_graph(self, graph, global_step=None):
-        """Record a model/graph description.  TF stores a GraphDef here; we store a JSON description of
-        the layer stack (TensorBoard ignores what it cannot parse, the scalars stay readable)."""
+        """``writer.add_graph(sess.graph)`` (/root/reference/example.py:195): a serialized ``tensorflow.GraphDef`` in
+        the event's ``graph_def`` field, which TensorBoard's graph tab parses.  ``graph`` may be a compat graph, an
+        engine, a ``Sequential``, a list of ``graph_def.Node`` or serialized GraphDef bytes (see ``graph_def.nodes_for``)."""
         self._check()
-        if hasattr(graph, "get_config"):
-            desc = graph.get_config()
-        elif hasattr(graph, "as_graph_def"):
-            desc = graph.as_graph_def()
-        else:
-            desc = {"graph": repr(graph)}
-        data = desc if isinstance(desc, bytes) else json.dumps(desc, default=str).encode()
+        from . import graph_def as gd
+        data = bytes(graph) if isinstance(graph, (bytes, bytearray)) else gd.encode_graph_def(gd.nodes_for(graph))
         _rt().dtf_events_add_graph(self._h, data, len(data), 0.0)
 
     def add_histogram(self, tag: str, bucket_limits: Sequence[float], bucket_counts: Sequence[float],
