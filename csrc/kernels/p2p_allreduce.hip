@@ -14,7 +14,10 @@
 // The exchange buffers are the only memory shared between processes (hipIpc handles, opened once).  Double buffering
 // makes one flag round per call sufficient: a rank can only overwrite buffer p of call c+2 after every peer has
 // published call c+1, which each peer does after its own reduce of call c has completed in stream order.
-// The wait is bounded: a rank whose peers never show up sets an error word instead of spinning forever.
+// The wait is bounded (30 s by default, dtf_p2p_set_timeout_ms): ranks of a healthy job are routinely seconds apart
+// (the chief writing a checkpoint, first-step allocations), so the bound only has to beat "a peer is gone".  A rank
+// whose peers never show up sets an error word AND fills its output with NaN, so that a missed reduction can never
+// pass for a gradient; the strategy polls the error word and ends the rank.
 #include "common.h"
 
 #include <cstring>
@@ -22,7 +25,7 @@
 namespace {
 
 constexpr int MAX_RANKS = 16;
-constexpr long long SPIN_LIMIT = 400LL * 1000 * 1000;   // shader-clock ticks (~0.2 s) before giving up
+constexpr long long DEFAULT_SPIN_TICKS = 30LL * 100 * 1000 * 1000;   // 30 s of the 100 MHz wall clock
 
 struct Peers {
     float* data[MAX_RANKS];        // exchange buffers: [2][capacity] floats each
@@ -38,6 +41,7 @@ struct Comm {
     Peers peers = {};
     unsigned call = 0;
     bool fine_grained = false;
+    long long spin_ticks = DEFAULT_SPIN_TICKS;
 };
 
 __device__ __forceinline__ void store_system(unsigned* p, unsigned v) {
@@ -69,16 +73,16 @@ __global__ __launch_bounds__(256) void publish_kernel(const float* __restrict__ 
 
 __global__ __launch_bounds__(256) void reduce_kernel(float* __restrict__ out, long long n, Peers peers, int rank, int world,
                                                      unsigned call, int half, long long capacity,
-                                                     unsigned* __restrict__ error_word) {
+                                                     unsigned* __restrict__ error_word, long long spin_ticks) {
     __shared__ int ok;
     if (threadIdx.x == 0) {
         const unsigned* mine = peers.flags[rank];
-        const long long t0 = (long long)__builtin_readcyclecounter();
+        const long long t0 = (long long)wall_clock64();
         int good = 1;
         for (int r = 0; r < world; ++r) {
             // call numbers only grow; a wrapped counter is handled by the signed distance
             while ((int)(load_system(mine + r) - call) < 0) {
-                if ((long long)__builtin_readcyclecounter() - t0 > SPIN_LIMIT) { good = 0; break; }
+                if ((long long)wall_clock64() - t0 > spin_ticks) { good = 0; break; }
                 __builtin_amdgcn_s_sleep(8);
             }
             if (!good) break;
@@ -87,9 +91,18 @@ __global__ __launch_bounds__(256) void reduce_kernel(float* __restrict__ out, lo
         ok = good;
     }
     __syncthreads();
-    if (!ok) return;
-    const long long off = (long long)half * capacity;
     const long long n4 = n >> 2;
+    if (!ok) {
+        // a peer never published: poison the output instead of leaving the local gradient in place
+        const float nan = __builtin_nanf("");
+        const f32x4 nan4 = {nan, nan, nan, nan};
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x)
+            reinterpret_cast<f32x4*>(out)[i] = nan4;
+        if (blockIdx.x == 0)
+            for (long long i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) out[i] = nan;
+        return;
+    }
+    const long long off = (long long)half * capacity;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         for (int r = 0; r < world; ++r) {
@@ -188,9 +201,14 @@ DTF_API int dtf_p2p_allreduce(void* h, float* inout, long long n, hipStream_t st
                        call, done_counter);
     DTF_CHECK_LAUNCH();
     hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, inout, n, c->peers, c->rank, c->world, call,
-                       half, c->capacity, error_word);
+                       half, c->capacity, error_word, c->spin_ticks);
     DTF_CHECK_LAUNCH();
     return 0;
+}
+
+// How long a reduce waits for its peers before it gives up (milliseconds; the default is 30 s).
+DTF_API void dtf_p2p_set_timeout_ms(void* h, long long ms) {
+    if (ms > 0) static_cast<Comm*>(h)->spin_ticks = ms * 100 * 1000;       // 100 MHz wall clock
 }
 
 // Non-zero after a reduce gave up waiting for a peer (the value is the call number); reading it synchronises the

@@ -384,10 +384,15 @@ class GraphEngine(ModelEngine):
         wdev = "/job:worker/task:%d" % srv.task_index if srv is not None and srv.job_name == "worker" else ""
         setter = self.graph.device_setter
 
+        placed = {}
+        if setter is not None and setter.ps_tasks > 0:
+            # creation order as in the reference script: the layers' variables, then global_step
+            order = [(v.name, v.numel * 4) for v in self.model.store.trainable] + [("global_step", 8)]
+            placed = setter.place_variables(order)
+
         def vdev(name: str) -> str:
-            if setter is not None and setter.ps_tasks > 0:
-                return setter("Variable", name=name)          # round-robin in creation order, like TF
-            return wdev
+            k = placed.get(name)
+            return wdev if k is None or k < 0 else "/job:ps/task:%d" % k
         return gd.model_nodes(self.model, worker_device=wdev, variable_device=vdev,
                               loss_name=getattr(self.model.loss, "name", None),
                               optimizer_name=getattr(self.model.optimizer, "name", None),

@@ -545,6 +545,8 @@ class AsyncPSStrategy:
         self.versions: List[int] = []
         self.staleness_hist: Dict[int, int] = {}
         self.last_global_step = 0
+        self.comm_seconds = 0.0       # host time spent in the gradient push / parameter pull of every step
+        self.wait_seconds = 0.0       # host time blocked by the staleness bound
         self._service = None
         self._service_thread = None
         self._cps: List[ControlClient] = []
@@ -767,6 +769,7 @@ class AsyncPSStrategy:
     def apply_gradients(self, model):
         """Push this step's gradients to every owner and pull the refreshed parameters back."""
         store = model.store
+        t_begin = time.perf_counter()
         if self.region is not None:
             for j in range(self.num_owners):
                 b, e = self.ranges[j][0]
@@ -797,9 +800,12 @@ class AsyncPSStrategy:
         if self.last_global_step:
             store.global_step.fill_(self.last_global_step)
         self.clock += 1
+        t_comm = time.perf_counter()
+        self.comm_seconds += t_comm - t_begin
         if self.max_staleness is not None:
             # publish the new clock and wait for permission to start the next step, in one round trip
             self.cp0.clock_set_wait("workers", self.worker_index, self.clock, self.max_staleness, timeout_s=self.timeout_s)
+            self.wait_seconds += time.perf_counter() - t_comm
 
     def global_step(self) -> int:
         """Cluster-wide global step (one control-plane round trip)."""

@@ -34,15 +34,20 @@ def _k():
         nv.declare(lib, "dtf_p2p_open_peers", [p, p])
         nv.declare(lib, "dtf_p2p_allreduce", [p, p, i64, p])
         nv.declare(lib, "dtf_p2p_error", [p])
+        nv.declare(lib, "dtf_p2p_set_timeout_ms", [p, i64], None)
         nv.declare(lib, "dtf_p2p_destroy", [p], None)
         _lib = lib
     return _lib
 
 
+class P2PTimeoutError(RuntimeError):
+    """A rank of the node never took part in a peer-pointer all-reduce."""
+
+
 class P2PAllReduce:
     """``capacity`` floats can be reduced per call.  Construction is collective over ``group``."""
 
-    def __init__(self, capacity: int, device, group=None):
+    def __init__(self, capacity: int, device, group=None, timeout_s: Optional[float] = None):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.group = group if group is not None else dist.group.WORLD
@@ -67,6 +72,10 @@ class P2PAllReduce:
             if rc:
                 raise RuntimeError("hipIpcOpenMemHandle failed (%d)" % rc)
         self.capacity = int(capacity)
+        import os
+        timeout_s = float(os.environ.get("DTF_P2P_TIMEOUT_SECS", "30")) if timeout_s is None else timeout_s
+        lib.dtf_p2p_set_timeout_ms(self._h, int(timeout_s * 1000))
+        self.timeout_s = timeout_s
         self.fine_grained = bool(lib.dtf_p2p_is_fine_grained(self._h))
         dist.barrier(group=self.group) if dist.get_backend(self.group) != "nccl" else \
             dist.barrier(group=self.group, device_ids=[self.device.index])
@@ -80,10 +89,12 @@ class P2PAllReduce:
             raise RuntimeError("peer-pointer all-reduce refused the call (%d)" % rc)
 
     def check(self) -> None:
-        """Raise if a reduce gave up waiting for a peer (synchronises the device: for occasional use)."""
+        """Raise if a reduce gave up waiting for a peer (synchronises the device: for occasional use).  The output of
+        such a reduce is all NaN; the error is permanent - the rank must be restarted with its gang."""
         e = _k().dtf_p2p_error(self._h)
         if e:
-            raise RuntimeError("peer-pointer all-reduce: a peer never published call %d" % e)
+            raise P2PTimeoutError("peer-pointer all-reduce: a peer did not publish call %d within %.1f s; its result "
+                                  "is NaN and this rank cannot continue" % (e, self.timeout_s))
 
     def close(self):
         h, self._h = self._h, None

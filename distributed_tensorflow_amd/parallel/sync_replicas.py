@@ -62,6 +62,13 @@ class SyncReplicasStrategy:
         # sharded apply in between - one collective launch per step instead of two, nothing to gather afterwards.
         self.allreduce_below_bytes = int(allreduce_below_bytes)
         self.replicated = False
+        self.p2p = None
+        self.p2p_check_every = int(os.environ.get("DTF_P2P_CHECK_EVERY", "50"))
+        # DTF_TIME_COMM=1: bracket every gradient exchange with stream events (GPU) or a host timer (CPU) and report
+        # the total through comm_seconds(); events are resolved lazily, so timing adds no synchronisation
+        self.time_comm = os.environ.get("DTF_TIME_COMM", "0") == "1"
+        self._comm_total = 0.0
+        self._comm_pending: List = []
         self.buckets: List[_Bucket] = []
         self._layer_bucket: Dict[int, _Bucket] = {}
         # exercise the real collectives even with one rank (GPU-box test of the RCCL path)
@@ -156,9 +163,44 @@ class SyncReplicasStrategy:
         if b.pending == 0:
             self._launch(b, model.store)
 
+    # ------------------------------------------------------------------ communication time
+    def _comm_begin(self, store):
+        if not self.time_comm:
+            return None
+        if store.device.type == "cuda":
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            return e
+        import time
+        return time.perf_counter()
+
+    def _comm_end(self, store, begin):
+        if begin is None:
+            return
+        if store.device.type == "cuda":
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self._comm_pending.append((begin, e))
+        else:
+            import time
+            self._comm_total += time.perf_counter() - begin
+
+    def comm_seconds(self) -> float:
+        """Time spent in gradient exchanges so far (only with ``DTF_TIME_COMM=1``); exchanges still in flight are
+        counted at a later call."""
+        keep = []
+        for b, e in self._comm_pending:
+            if e.query():
+                self._comm_total += b.elapsed_time(e) * 1e-3
+            else:
+                keep.append((b, e))
+        self._comm_pending = keep
+        return self._comm_total
+
     def _apply_replicated(self, model, scale):
         store = model.store
         c = self.comm
+        t_comm = self._comm_begin(store)
         if self.world_size > 1 or self.force:
             # a blocking-style call (async_op=False) orders the collective against the compute stream without the
             # event hops to and from RCCL's side stream that an async op plus wait() costs (12 us per step measured
@@ -170,10 +212,17 @@ class SyncReplicasStrategy:
             elif getattr(self, "p2p", None) is not None:
                 self.p2p.all_reduce_sum(store.flat_grad)
                 work = None
+                # a reduce that gave up on a peer has poisoned the gradient with NaN and set an error word; reading
+                # it synchronises the device, so it is polled every `p2p_check_every` steps (and before anything is
+                # broadcast or saved) - the rank then raises and the launcher restarts the gang
+                self._p2p_calls = getattr(self, "_p2p_calls", 0) + 1
+                if self._p2p_calls % self.p2p_check_every == 0:
+                    self.p2p.check()
             else:
                 work = c.all_reduce_sum(store.flat_grad, async_op=use_async)
             if work is not None and hasattr(work, "wait"):
                 work.wait()            # stream-level wait under RCCL: the host does not block
+        self._comm_end(store, t_comm)
         model.optimizer.apply_and_finish(store, grad_scale=scale)
 
     def apply_gradients(self, model):
@@ -217,8 +266,14 @@ class SyncReplicasStrategy:
         self.comm.all_reduce_sum(s)
         return s
 
+    def check_exchange(self):
+        """Raise if the peer-pointer gradient exchange has lost a rank (no-op for the RCCL exchange)."""
+        if getattr(self, "p2p", None) is not None:
+            self.p2p.check()
+
     def broadcast_state(self, model):
         """Chief-initialises / others-wait: the chief's variables, slots and step win on every replica."""
+        self.check_exchange()
         store = model.store
         self.comm.broadcast(store.flat, 0)
         self.comm.broadcast(store.global_step, 0)
@@ -229,6 +284,7 @@ class SyncReplicasStrategy:
     def gather_slots(self, model):
         """Collective: make every replica's optimizer-slot buffers complete (each replica only updates the
         slots of the shards it owns), so that the chief can write a full checkpoint."""
+        self.check_exchange()                             # never checkpoint past a failed gradient exchange
         if self.world_size == 1 or self.replicated:      # replicated apply keeps every slot complete everywhere
             return
         store = model.store

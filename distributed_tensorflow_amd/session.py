@@ -139,6 +139,59 @@ class StepCounterHook(SessionRunHook):
             self.writer.flush()
 
 
+class StepLatencyHook(SessionRunHook):
+    """Step-latency percentiles and communication time, every N steps, as scalars next to ``global_step/sec``:
+    ``step_latency_ms/p50|p90|p99|max`` (host wall time of one ``run``: exact when the run fetches something from the
+    device - the reference fetches loss and accuracy every step - and the enqueue time of the step otherwise) and, when
+    the strategy keeps the counters, ``comm_ms/step`` (time in the gradient exchange per step) and
+    ``staleness_wait_ms/step`` (time blocked by the staleness bound)."""
+
+    def __init__(self, every_n_steps: int = 100, summary_writer=None, output_dir: Optional[str] = None, log=None):
+        self.every, self.writer, self.output_dir, self.log = every_n_steps, summary_writer, output_dir, log
+        self._lat: List[float] = []
+        self._t0 = None
+        self._comm0 = self._wait0 = 0.0
+        self.last: Dict[str, float] = {}
+
+    def after_create_session(self, session, coord):
+        if self.writer is None and self.output_dir:
+            self.writer = summary_mod.FileWriterCache.get(self.output_dir)
+
+    def before_run(self, run_context):
+        self._t0 = time.perf_counter()
+        return None
+
+    @staticmethod
+    def percentiles(samples: Sequence[float]) -> Dict[str, float]:
+        xs = sorted(samples)
+        pick = lambda q: xs[min(len(xs) - 1, int(q * len(xs)))]
+        return {"p50": pick(0.50), "p90": pick(0.90), "p99": pick(0.99), "max": xs[-1]}
+
+    def after_run(self, run_context, run_values):
+        self._lat.append((time.perf_counter() - self._t0) * 1e3)
+        if len(self._lat) < self.every:
+            return
+        sess = run_context.session
+        vals = [("step_latency_ms/" + k, v) for k, v in self.percentiles(self._lat).items()]
+        st = getattr(sess.engine, "strategy", None)
+        for name, attr, prev in (("comm_ms/step", "comm_seconds", "_comm0"), ("staleness_wait_ms/step", "wait_seconds", "_wait0")):
+            tot = getattr(st, attr, None)
+            if tot is not None:
+                tot = float(tot() if callable(tot) else tot)
+                vals.append((name, (tot - getattr(self, prev)) * 1e3 / len(self._lat)))
+                setattr(self, prev, tot)
+        self.last = dict(vals)
+        if self.writer is not None:
+            self.writer.add_summary(summary_mod.Summary(vals), sess.global_step_value())
+        if self.log:
+            self.log("INFO: " + ", ".join("%s = %.3f" % kv for kv in vals))
+        self._lat = []
+
+    def end(self, session):
+        if self.writer is not None:
+            self.writer.flush()
+
+
 class SummarySaverHook(SessionRunHook):
     """Evaluate ``summary_op`` (default: ``merge_all()``) every N steps and write it at the true global step."""
 
@@ -441,6 +494,7 @@ def MonitoredTrainingSession(master: str = "", is_chief: bool = True, checkpoint
     if is_chief and checkpoint_dir:
         if log_step_count_steps:
             all_hooks.append(StepCounterHook(every_n_steps=log_step_count_steps, output_dir=checkpoint_dir, log=None))
+            all_hooks.append(StepLatencyHook(every_n_steps=log_step_count_steps, output_dir=checkpoint_dir))
         if save_summaries_steps:
             all_hooks.append(SummarySaverHook(save_steps=save_summaries_steps, output_dir=checkpoint_dir,
                                               summary_op=scaffold.summary_op if scaffold else None))

@@ -9,11 +9,45 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from distributed_tensorflow_amd.parallel.p2p_allreduce import P2PAllReduce  # noqa: E402
 
 
+def delayed_rank(rank, world, dev):
+    """A rank that shows up later than the timeout: the waiting ranks' result is NaN (never the local gradient) and
+    their error check raises; the late rank itself still finds everybody's contribution."""
+    import time
+    from distributed_tensorflow_amd.parallel.p2p_allreduce import P2PTimeoutError
+    ar = P2PAllReduce(4096, dev, timeout_s=0.3)
+    t = torch.full((4096,), float(rank + 1), device=dev)
+    ar.all_reduce_sum(t)                        # a normal call first
+    torch.cuda.synchronize()
+    assert torch.equal(t.cpu(), torch.full((4096,), world * (world + 1) / 2.0))
+    dist.barrier()
+    if rank == world - 1:
+        time.sleep(1.5)
+    t = torch.full((4096,), float(rank + 1), device=dev)
+    ar.all_reduce_sum(t)
+    torch.cuda.synchronize()
+    if rank == world - 1:
+        assert torch.equal(t.cpu(), torch.full((4096,), world * (world + 1) / 2.0))
+        ar.check()
+    else:
+        assert torch.isnan(t).all(), t[:4]
+        try:
+            ar.check()
+            raise AssertionError("check() did not report the missed reduction")
+        except P2PTimeoutError:
+            pass
+    dist.barrier()
+    print("P2P_OK rank %d delayed" % rank, flush=True)
+    ar.close()
+    dist.destroy_process_group()
+
+
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % os.environ["MASTER_PORT"], rank=rank, world_size=world)
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
+    if os.environ.get("P2P_DELAY_TEST") == "1":
+        return delayed_rank(rank, world, dev)
     cap = 120000
     ar = P2PAllReduce(cap, dev)
     g = torch.Generator().manual_seed(1234)             # same stream of sizes on every rank

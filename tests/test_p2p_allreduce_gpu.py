@@ -15,14 +15,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKER = os.path.join(ROOT, "tests", "_p2p_worker.py")
 
 
+def test_a_late_rank_poisons_the_result_and_is_reported(tmp_path):
+    """One rank arrives 1.5 s late with a 0.3 s timeout: the others get NaN (not their local gradient) and
+    ``check()`` raises."""
+    test_ranks_on_one_gpu_reduce_through_mapped_buffers(2, tmp_path, extra_env={"P2P_DELAY_TEST": "1"})
+
+
 @pytest.mark.parametrize("world", [2, 3])
-def test_ranks_on_one_gpu_reduce_through_mapped_buffers(world, tmp_path):
+def test_ranks_on_one_gpu_reduce_through_mapped_buffers(world, tmp_path, extra_env=None):
     port = _ports(1)[0]
     procs, logs = [], []
     try:
         for r in range(world):
             env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_PORT=str(port), PYTHONFAULTHANDLER="1",
-                       HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+                       HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", **(extra_env or {}))
             logs.append(open(str(tmp_path / ("rank%d.log" % r)), "w+"))
             procs.append(subprocess.Popen([sys.executable, WORKER], env=env, stdout=logs[-1], stderr=subprocess.STDOUT))
         failed = None

@@ -170,3 +170,29 @@ def test_hooks_share_one_step_read_per_run_and_no_device_sync(tmp_path, monkeypa
             sess.run(TRAIN_OP, {"x": x, "y": y})
         assert sess.step_reads - s0 == 20                   # one shared read per run ...
         assert reads == []                                  # ... served from the host mirror: no tensor was read back
+
+
+def test_step_latency_percentiles_and_comm_time(tmp_path):
+    sm.FileWriterCache.clear()
+    m, eng = make()
+    m.strategy.comm_seconds = 0.0                    # a strategy that keeps the counter
+    hook = ss.StepLatencyHook(every_n_steps=10, output_dir=str(tmp_path))
+    orig = eng.run
+
+    def run(f, fd=None):
+        m.strategy.comm_seconds += 0.002
+        return orig(f, fd)
+    eng.run = run
+    with ss.MonitoredSession(eng, hooks=[hook, ss.StopAtStepHook(last_step=20)]) as sess:
+        loop(sess)
+    assert set(hook.last) == {"step_latency_ms/p50", "step_latency_ms/p90", "step_latency_ms/p99", "step_latency_ms/max",
+                              "comm_ms/step"}
+    assert hook.last["step_latency_ms/p50"] <= hook.last["step_latency_ms/p99"] <= hook.last["step_latency_ms/max"]
+    assert abs(hook.last["comm_ms/step"] - 2.0) < 1e-6
+    assert ss.StepLatencyHook.percentiles(list(range(1, 101))) == {"p50": 51, "p90": 91, "p99": 100, "max": 100}
+    sm.FileWriterCache.clear()
+    (path,) = glob.glob(os.path.join(str(tmp_path), "events.out.tfevents.*"))
+    tags = set()
+    for e in sm.read_events(path):
+        tags |= set(e.get("scalars", {}))
+    assert {"step_latency_ms/p99", "comm_ms/step"} <= tags
