@@ -539,6 +539,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // does this wave own any output inside C?  (TM x TN sub-tiles starting at its first row / column)
+    const bool wave_live = (m0 + wm * TM * 32 < p.M) && (n0 + wn * TN * 32 < p.N);
     float csum = 0.f;  // wgrad: partial bias gradient of column n0 + tid
     const bool do_colsum = (EPI == EPI_DW) && (p.colsum != nullptr) && (blockIdx.y == 0);
 
@@ -570,6 +572,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) fb[0][j] = read_frag<BN, B_KC>(Bs, (wn * TN + j) * 32 + li, 0, h);
     }
+    // The loop exists in two compiled versions: with MFMAs, and - for a wave whose 32-row / 32-column sub-tiles lie
+    // entirely past M / N (half the waves of the last row tile of a 784-row wgrad) - without: such a wave keeps loading
+    // and synchronising with its block but leaves the matrix pipe to the co-resident waves.  (A run-time test around
+    // the MFMAs inside ONE loop costs the compiler its schedule: measured +40 % on the wgrad kernel.)
+    auto main_loop = [&](auto live_tag) {
+    constexpr bool LIVE = decltype(live_tag)::value;
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         const bool more = (k0 + BK) < kend;
         const float* As = smem + stage * STAGE;
@@ -584,11 +592,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
             const int cur = kk & 1, nxt = cur ^ 1;
             // step t = 0 first: whatever wait precedes it only concerns reads issued a whole k-group ago
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (LIVE) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][0], fb[cur][j][0], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][0], fb[cur][j][0], acc[i][j], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
             if (kk < LAST) {
 #pragma unroll
@@ -619,17 +629,22 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
                 for (int j = 0; j < TN; ++j) fb[nxt][j] = read_frag<BN, B_KC>(Bn, (wn * TN + j) * 32 + li, 0, h);
             }
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (LIVE) {
 #pragma unroll
-            for (int t = 1; t < 4; ++t)
+                for (int t = 1; t < 4; ++t)
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                    for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][t], fb[cur][j][t], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][t], fb[cur][j][t], acc[i][j], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         stage ^= 1;
     }
+    };
+    if (wave_live) main_loop(std::true_type{});
+    else main_loop(std::false_type{});
 
     unsigned long long dbg_t1 = 0;
     if (p.dbg & 8) dbg_t1 = __builtin_amdgcn_s_memtime();
