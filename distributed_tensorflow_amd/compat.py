@@ -90,12 +90,72 @@ class Operation(Tensor):
     """A node run for its effect (training op, initializer); fetching it yields ``None``."""
 
 
+class InitialValue:
+    """What ``tf.random_normal(shape, ...)`` / ``tf.zeros(shape)`` ... return: a shape plus the recipe that fills it
+    (drawn from the model's seeded generator when the graph is lowered).  Only meaningful as the initial value of a
+    ``tf.Variable``."""
+
+    def __init__(self, shape, kind: str, **params):
+        self.shape = tuple(int(s) for s in shape)
+        self.kind = kind
+        self.params = params
+
+    def __call__(self, shape, generator=None) -> torch.Tensor:
+        shape = tuple(shape)
+        p = self.params
+        if self.kind == "zeros":
+            return torch.zeros(shape)
+        if self.kind == "ones":
+            return torch.ones(shape)
+        if self.kind == "constant":
+            return torch.full(shape, float(p["value"])) if not isinstance(p["value"], torch.Tensor) \
+                else p["value"].to(torch.float32).reshape(shape).clone()
+        if self.kind == "random_normal":
+            return torch.randn(shape, generator=generator) * p["stddev"] + p["mean"]
+        if self.kind == "truncated_normal":       # values beyond two standard deviations are re-drawn
+            t = torch.randn(shape, generator=generator)
+            for _ in range(8):
+                bad = t.abs() > 2.0
+                if not bad.any():
+                    break
+                t = torch.where(bad, torch.randn(shape, generator=generator), t)
+            return t.clamp_(-2.0, 2.0) * p["stddev"] + p["mean"]
+        if self.kind == "random_uniform":
+            return torch.rand(shape, generator=generator) * (p["maxval"] - p["minval"]) + p["minval"]
+        if self.kind == "glorot_uniform":
+            from .variables import glorot_uniform
+            return glorot_uniform(shape, generator)
+        raise ValueError("unknown initial value kind %r" % self.kind)
+
+
+def zeros(shape, dtype=None, name=None): return InitialValue(shape, "zeros")
+def ones(shape, dtype=None, name=None): return InitialValue(shape, "ones")
+def random_normal(shape, mean=0.0, stddev=1.0, dtype=None, seed=None, name=None):
+    return InitialValue(shape, "random_normal", mean=float(mean), stddev=float(stddev))
+def truncated_normal(shape, mean=0.0, stddev=1.0, dtype=None, seed=None, name=None):
+    return InitialValue(shape, "truncated_normal", mean=float(mean), stddev=float(stddev))
+def random_uniform(shape, minval=0.0, maxval=1.0, dtype=None, seed=None, name=None):
+    return InitialValue(shape, "random_uniform", minval=float(minval), maxval=float(maxval))
+def glorot_uniform_initializer(seed=None, dtype=None):
+    return lambda shape, dtype=None, partition_info=None: InitialValue(shape, "glorot_uniform")
+
+
+def constant(value, dtype=None, shape=None, name=None):
+    t = torch.as_tensor(value, dtype=torch.float32)
+    return InitialValue(tuple(shape) if shape is not None else tuple(t.shape), "constant",
+                        value=float(t) if t.dim() == 0 else t)
+
+
 class VariableNode(Tensor):
-    """``tf.Variable``: only non-trainable scalars are created by scripts (``global_step``)."""
+    """``tf.Variable``.  Non-trainable scalars (``global_step``) are counters of the engine; a trainable variable
+    with an ``InitialValue`` (or array) becomes a weight or bias of the layer that ``tf.matmul`` / ``+`` wire it into."""
 
     def __init__(self, initial_value, dtype=None, name=None, trainable=True):
+        if not isinstance(initial_value, InitialValue) and trainable and not isinstance(initial_value, (int, float)):
+            initial_value = constant(initial_value)
+        shape = initial_value.shape if isinstance(initial_value, InitialValue) else ()
         super().__init__("Variable", [], {"initial_value": initial_value, "dtype": dtype, "trainable": trainable},
-                         name=name or "Variable")
+                         name=name or "Variable", shape=shape)
 
 
 class Graph:
@@ -213,6 +273,25 @@ def argmax(x, axis=None, name=None): return Tensor("argmax", [x], {"axis": axis}
 def reduce_mean(x, axis=None, name=None): return Tensor("reduce_mean", [x], {"axis": axis}, name=name)
 def reduce_sum(x, axis=None, name=None): return Tensor("reduce_sum", [x], {"axis": axis}, name=name)
 def sigmoid(x, name=None): return Tensor("sigmoid", [x], name=name)
+def matmul(a, b, transpose_a=False, transpose_b=False, name=None):
+    if transpose_a or transpose_b:
+        raise NotImplementedError("tf.matmul: transposed operands are not supported by the graph front end")
+    return Tensor("matmul", [a, b], name=name or "MatMul")
+def add(x, y, name=None): return Tensor("add", [x, y], name=name)
+def _bias_add(value, bias, name=None): return Tensor("bias_add", [value, bias], name=name or "BiasAdd")
+def _relu(x, name=None): return Tensor("relu", [x], name=name or "Relu")
+def _softmax(x, name=None, **_): return Tensor("softmax", [x], name=name or "Softmax")
+def _nn_dropout(x, keep_prob, noise_shape=None, seed=None, name=None):
+    if not isinstance(keep_prob, (int, float)):
+        raise NotImplementedError("tf.nn.dropout: keep_prob must be a Python number here (training / evaluation is "
+                                  "switched with K.learning_phase(), as in the reference script)")
+    return Tensor("nn_dropout", [x], {"keep_prob": float(keep_prob)}, name=name or "dropout")
+
+
+def _layers_dense(inputs, units, activation=None, use_bias=True, kernel_initializer=None, name=None, **_):
+    """``tf.layers.dense``: the functional spelling of ``keras.layers.Dense(units, activation)(inputs)``."""
+    act = {None: None, _relu: "relu", sigmoid: "sigmoid", _softmax: "softmax"}.get(activation, activation)
+    return _Dense(units, activation=act, use_bias=use_bias, name=name)(inputs)
 
 
 def _eval_generic(node, env: Dict[Tensor, torch.Tensor], engine: "GraphEngine", training: bool):
@@ -221,6 +300,16 @@ def _eval_generic(node, env: Dict[Tensor, torch.Tensor], engine: "GraphEngine", 
         return node
     if node in env:
         return env[node]
+    low = getattr(engine, "lowered", {}).get(node)
+    if low is not None:
+        # the last node of a hand-written op group (matmul [+ bias] [+ activation]): evaluate the layer it became
+        layer, src = low
+        out = layer.forward(_eval_generic(src, env, engine, training), training)
+        if isinstance(layer, _layers.Dense) and layer.softmax and layer.emit_logits and node.op == "softmax":
+            from .ops import functional as F
+            out = F.softmax(out)
+        env[node] = out
+        return out
     op = node.op
     ins = [_eval_generic(i, env, engine, training) for i in node.inputs]
     if op == "Placeholder":
@@ -240,6 +329,11 @@ def _eval_generic(node, env: Dict[Tensor, torch.Tensor], engine: "GraphEngine", 
     elif op == "mul": out = ins[0] * ins[1]
     elif op == "div": out = ins[0] / ins[1]
     elif op == "sigmoid": out = torch.sigmoid(ins[0])
+    elif op == "relu": out = torch.relu(ins[0])
+    elif op == "softmax": out = torch.softmax(ins[0], dim=-1)
+    elif op == "matmul": out = ins[0] @ ins[1]
+    elif op == "bias_add": out = ins[0] + ins[1]
+    elif op == "nn_dropout": out = ins[0]          # evaluation outside the training path: identity
     elif op == "argmax": out = ins[0].argmax(dim=node.attrs["axis"] if node.attrs["axis"] is not None else 0)
     elif op == "reduce_mean":
         out = ins[0].float().mean() if node.attrs["axis"] is None else ins[0].float().mean(dim=node.attrs["axis"])
@@ -283,15 +377,9 @@ class GraphEngine(ModelEngine):
             raise ValueError("the graph has no training op (optimizer.minimize(loss) was never called)")
         loss_name, labels, preds = self._match_loss(self.loss_node)
         self.labels, self.preds = labels, preds
-        chain = []
-        node = preds
-        while _match(node, "layer"):
-            chain.append(node.attrs["layer"])
-            node = node.inputs[0]
-        if not _match(node, "Placeholder"):
-            raise NotImplementedError("the model must be a chain of layers applied to a placeholder")
+        self.lowered: Dict[Tensor, Any] = {}
+        chain, node = self._lower_chain(preds)
         self.input = node
-        chain.reverse()
         if node.shape is None or len(node.shape) < 2:
             raise ValueError("input placeholder needs a (None, features...) shape")
         model = _Sequential(chain, name="graph_model")
@@ -309,6 +397,67 @@ class GraphEngine(ModelEngine):
                       strategy=strategy, device=_pick_device(), seed=self.graph.__dict__.get("seed"))
         self.model = model
         self.graph.finalize()
+
+    def _lower_chain(self, preds):
+        """Walk from the model output back to its input placeholder and turn what is found into layers: Keras layer
+        calls as they are, and hand-written groups ``act(tf.matmul(x, W) + b)`` / ``tf.nn.bias_add`` /
+        ``tf.nn.dropout`` / a lone activation into ``Dense`` / ``Dropout`` / ``Activation`` layers that keep the
+        script's variable names and initial values.  Returns (layers in forward order, input placeholder)."""
+        chain = []
+        node = preds
+        while not _match(node, "Placeholder"):
+            if not isinstance(node, Tensor):
+                raise NotImplementedError("the model output must be computed from a placeholder, found %r" % (node,))
+            if node.op == "layer":
+                chain.append(node.attrs["layer"])
+                node = node.inputs[0]
+                continue
+            if node.op == "nn_dropout":
+                layer = _layers.Dropout(1.0 - node.attrs["keep_prob"])
+                chain.append(layer)
+                self.lowered[node] = (layer, node.inputs[0])
+                node = node.inputs[0]
+                continue
+            if node.op not in ("relu", "sigmoid", "softmax", "add", "bias_add", "matmul"):
+                raise NotImplementedError(
+                    "op %r (node %r) is not supported on the model path: the graph front end lowers chains of Keras "
+                    "layers, tf.layers.dense, tf.matmul(x, W) [+ b / tf.nn.bias_add] [tf.nn.relu | tf.sigmoid | "
+                    "tf.nn.softmax] and tf.nn.dropout applied to one placeholder" % (node.op, node.name))
+            top, act, n = node, None, node
+            if n.op in ("relu", "sigmoid", "softmax"):
+                act, n = n.op, n.inputs[0]
+            bias = None
+            if _match(n, "add") or _match(n, "bias_add"):
+                a, b = n.inputs
+                if isinstance(b, VariableNode) and len(b.shape) == 1:
+                    bias, n = b, a
+                elif isinstance(a, VariableNode) and len(a.shape) == 1:
+                    bias, n = a, b
+                else:
+                    raise NotImplementedError("node %r adds two activations: only `matmul + bias variable` is supported "
+                                              "(no skip connections)" % n.name)
+            if not _match(n, "matmul"):
+                if act is None or bias is not None:
+                    raise NotImplementedError("node %r: a bias without a tf.matmul in front of it" % top.name)
+                layer = _layers.Activation(act)          # a lone activation after some other layer
+                chain.append(layer)
+                self.lowered[top] = (layer, n)
+                node = n
+                continue
+            x, w = n.inputs
+            if not (isinstance(w, VariableNode) and w.attrs["trainable"] and len(w.shape) == 2):
+                raise NotImplementedError("tf.matmul(%r, %r): the second operand must be a trainable 2-D tf.Variable"
+                                          % (getattr(x, "name", x), getattr(w, "name", w)))
+            layer = _layers.Dense(int(w.shape[1]), activation=act, use_bias=bias is not None,
+                                  kernel_initializer=w.attrs["initial_value"],
+                                  bias_initializer=bias.attrs["initial_value"] if bias is not None else "zeros")
+            layer.kernel_name = w.name
+            layer.bias_name = bias.name if bias is not None else None
+            chain.append(layer)
+            self.lowered[top] = (layer, x)
+            node = x
+        chain.reverse()
+        return chain, node
 
     def _pick_strategy(self, opt_node):
         srv = _cluster.current_server()
@@ -351,7 +500,7 @@ class GraphEngine(ModelEngine):
         if _match(node, "reduce_mean") and _match(node.inputs[0], "square") and _match(node.inputs[0].inputs[0], "sub"):
             s = node.inputs[0].inputs[0]
             a, b = s.inputs
-            preds, labels = (a, b) if _match(a, "layer") else (b, a)
+            preds, labels = (b, a) if _match(a, "Placeholder") else (a, b)      # the fed operand is the label
             return "mean_squared_error", labels, preds
         raise NotImplementedError(
             "minimize() supports reduce_mean of keras.losses.mean_squared_error, tf.square(a - b), "
@@ -401,6 +550,9 @@ class GraphEngine(ModelEngine):
     def variable_value(self, node):
         if node is self.global_step_node or node.name.endswith("global_step"):
             return self.global_step_value()
+        v = self.model.store.variables.get(node.name) if self.model is not None else None
+        if v is not None:
+            return v.tensor
         raise KeyError("variable %s has no value in this graph" % node.name)
 
     def resolve(self, fetch):
@@ -537,7 +689,8 @@ def _sparse_softmax_xent(labels=None, logits=None, name=None, **_):
 nn = types.SimpleNamespace(softmax_cross_entropy_with_logits=_softmax_xent,
                            softmax_cross_entropy_with_logits_v2=_softmax_xent,
                            sparse_softmax_cross_entropy_with_logits=_sparse_softmax_xent,
-                           sigmoid=sigmoid)
+                           sigmoid=sigmoid, relu=_relu, softmax=_softmax, bias_add=_bias_add, dropout=_nn_dropout)
+layers = types.SimpleNamespace(dense=_layers_dense)
 
 summary = types.SimpleNamespace(scalar=_summary.scalar, merge_all=_summary.merge_all, merge=_summary.merge,
                                 FileWriter=_summary.FileWriter, Summary=_summary.Summary)

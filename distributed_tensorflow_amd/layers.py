@@ -115,6 +115,10 @@ class Dense(Layer):
         self.bias_initializer = bias_initializer
         self.kernel = None
         self.bias = None
+        # explicit variable names (a graph written with tf.Variable / tf.matmul keeps the names of its variables in
+        # checkpoints); None = Keras naming, "<layer>/kernel" and "<layer>/bias"
+        self.kernel_name: Optional[str] = None
+        self.bias_name: Optional[str] = None
         self.fused_keep = 1.0        # keep-probability of a Dropout folded into the forward epilogue
         self.seed = _next_seed()
         # producing layer's gradient folded into this layer's dgrad epilogue
@@ -140,9 +144,9 @@ class Dense(Layer):
     def build(self, input_shape, store):
         out = super().build(input_shape, store)
         k = int(input_shape[0])
-        self.kernel = store.create(self.name + "/kernel", (k, self.units), self.kernel_initializer)
+        self.kernel = store.create(self.kernel_name or self.name + "/kernel", (k, self.units), self.kernel_initializer)
         if self.use_bias:
-            self.bias = store.create(self.name + "/bias", (self.units,), self.bias_initializer)
+            self.bias = store.create(self.bias_name or self.name + "/bias", (self.units,), self.bias_initializer)
         return out
 
     @property

@@ -108,3 +108,103 @@ def test_unsupported_loss_is_reported():
     tf.train.AdamOptimizer().minimize(loss)
     with pytest.raises(NotImplementedError):
         tf.get_default_graph().engine()
+
+
+def test_hand_written_matmul_graph_trains_and_keeps_variable_names(tmp_path):
+    """A TF1 script that spells its layers out - tf.Variable / tf.matmul / + / tf.nn.relu / tf.nn.dropout and a linear
+    head under softmax cross-entropy - lowers onto the same engine; checkpoints carry the script's variable names."""
+    import torch
+    from distributed_tensorflow_amd.data import mnist_like
+    tf.reset_default_graph()
+    tf.get_default_graph().seed = 7
+    x = tf.placeholder(tf.float32, shape=(None, 784))
+    y = tf.placeholder(tf.float32, shape=(None, 10))
+    W1 = tf.Variable(tf.truncated_normal([784, 64], stddev=0.05), name="W1")
+    b1 = tf.Variable(tf.zeros([64]), name="b1")
+    W2 = tf.Variable(tf.random_normal([64, 32], stddev=0.1), name="W2")
+    b2 = tf.Variable(tf.constant(0.1, shape=[32]), name="b2")
+    W3 = tf.Variable(tf.random_normal([32, 10], stddev=0.1), name="W3")
+    b3 = tf.Variable(tf.zeros([10]), name="b3")
+    h1 = tf.nn.dropout(tf.nn.relu(tf.matmul(x, W1) + b1), 0.8)
+    h2 = tf.nn.relu(tf.nn.bias_add(tf.matmul(h1, W2), b2))
+    logits = tf.add(tf.matmul(h2, W3), b3)
+    loss = tf.reduce_mean(tf.nn.softmax_cross_entropy_with_logits(labels=y, logits=logits))
+    accuracy = tf.reduce_mean(tf.cast(tf.equal(tf.argmax(logits, 1), tf.argmax(y, 1)), tf.float32))
+    global_step = tf.Variable(0, dtype=tf.int64, name="global_step", trainable=False)
+    train = tf.train.GradientDescentOptimizer(0.2).minimize(loss, global_step=global_step)
+    xs, ys = mnist_like(512, seed=1, one_hot=True)
+    losses = []
+    with tf.train.MonitoredTrainingSession(checkpoint_dir=str(tmp_path), hooks=[tf.train.StopAtStepHook(last_step=40)]) as sess:
+        eng = tf.get_default_graph().engine()
+        layers = eng.model.layers
+        assert [type(l).__name__ for l in layers] == ["Dense", "Dropout", "Dense", "Dense"]
+        assert [l.units for l in layers if hasattr(l, "units")] == [64, 32, 10] and layers[0].activation == "relu"
+        assert torch.allclose(eng.model.store.variables["b2"].tensor, torch.full((32,), 0.1))
+        assert float(eng.model.store.variables["W1"].tensor.abs().max()) <= 0.1 + 1e-6      # truncated at 2 sigma
+        i = 0
+        while not sess.should_stop():
+            lo = (i * 64) % 448
+            l, a, _ = sess.run([loss, accuracy, train], {x: xs[lo:lo + 64], y: ys[lo:lo + 64], K.learning_phase(): 1})
+            losses.append(l)
+            i += 1
+        acc = accuracy.eval({x: xs, y: ys, K.learning_phase(): 0}, session=sess)
+        out = sess.run(logits, {x: xs[:8], K.learning_phase(): 0})          # a hand-written node evaluates through its layer
+        assert out.shape == (8, 10)
+    assert losses[-1] < losses[0] and acc > 0.5
+    names = dict(list_variables(latest_checkpoint(str(tmp_path))))
+    assert names["W1"] == (784, 64) and names["b3"] == (10,) and names["global_step"] == ()
+    tf.reset_default_graph()
+
+
+def test_unsupported_op_on_the_model_path_is_named():
+    tf.reset_default_graph()
+    x = tf.placeholder(tf.float32, shape=(None, 8))
+    y = tf.placeholder(tf.float32, shape=(None, 4))
+    h = Dense(4)(x)
+    p = tf.square(h)                                   # not a layer, matmul group or activation
+    loss = tf.reduce_mean(tf.square(p - y))
+    tf.train.AdamOptimizer().minimize(loss)
+    with pytest.raises(NotImplementedError, match="op 'square'"):
+        tf.get_default_graph().engine()
+    tf.reset_default_graph()
+    # a skip connection: two activations added
+    x = tf.placeholder(tf.float32, shape=(None, 8))
+    y = tf.placeholder(tf.float32, shape=(None, 8))
+    h = Dense(8, activation="relu")(x)
+    loss = tf.reduce_mean(tf.square(tf.nn.relu(h + x) - y))
+    tf.train.AdamOptimizer().minimize(loss)
+    with pytest.raises(NotImplementedError, match="skip connections"):
+        tf.get_default_graph().engine()
+    tf.reset_default_graph()
+
+
+def test_tf_layers_dense_and_lone_activation():
+    tf.reset_default_graph()
+    x = tf.placeholder(tf.float32, shape=(None, 16))
+    y = tf.placeholder(tf.float32, shape=(None, 4))
+    h = tf.nn.relu(tf.layers.dense(x, 12))             # a lone activation after a layer -> Activation layer
+    p = tf.layers.dense(h, 4, activation=tf.sigmoid)
+    loss = tf.reduce_mean(tf.square(p - y))
+    tf.train.AdamOptimizer().minimize(loss)
+    eng = tf.get_default_graph().engine()
+    assert [type(l).__name__ for l in eng.model.layers] == ["_Dense", "Activation", "_Dense"]
+    tf.reset_default_graph()
+
+
+def test_sync_replicas_optimizer_refuses_a_partial_aggregate():
+    import torch.distributed as dist
+    from distributed_tensorflow_amd.parallel import init_process_group
+    from tests.test_sync_replicas_cpu import _free_port
+    tf.reset_default_graph()
+    x = tf.placeholder(tf.float32, shape=(None, 8))
+    y = tf.placeholder(tf.float32, shape=(None, 4))
+    loss = tf.reduce_mean(tf.square(Dense(4, activation="sigmoid")(x) - y))
+    opt = tf.train.SyncReplicasOptimizer(tf.train.AdamOptimizer(), replicas_to_aggregate=3, total_num_replicas=4)
+    opt.minimize(loss)
+    init_process_group("gloo", rank=0, world_size=1, master_addr="127.0.0.1", master_port=_free_port())
+    try:
+        with pytest.raises(ValueError, match="replicas_to_aggregate=3"):
+            tf.get_default_graph().engine()
+    finally:
+        dist.destroy_process_group()
+        tf.reset_default_graph()
