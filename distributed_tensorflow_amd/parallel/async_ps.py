@@ -204,11 +204,17 @@ class _P2P:
                 h = torch.empty(t.shape, dtype=t.dtype)
                 staged.append((t, h))
             by_group.setdefault(id(self._group(tag)), []).append(dist.P2POp(dist.irecv, h, src, group=self._group(tag), tag=tag))
-        works = []
-        for ops in by_group.values():
-            works += self._issue(ops)
-        for w in works:
-            w.wait()
+        try:
+            works = []
+            for ops in by_group.values():
+                works += self._issue(ops)
+            for w in works:
+                w.wait()
+        except RuntimeError as e:
+            # the transport reports a dead peer as a plain RuntimeError ("Connection closed by peer", an RCCL abort):
+            # for the training loop that is the loss of a task, whichever detector notices it first
+            from ..failure import ClusterLostError
+            raise ClusterLostError("data plane failed (%s)" % str(e).splitlines()[0][:200]) from e
         for t, h in staged:
             t.copy_(h)
 

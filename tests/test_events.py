@@ -111,8 +111,10 @@ def test_graph_def_of_the_reference_script_places_variables_round_robin():
     in creation order (TF's default strategy), ops stay on the worker."""
     from distributed_tensorflow_amd import compat as tf
     from distributed_tensorflow_amd import graph_def as gd
+    from distributed_tensorflow_amd import cluster
     from distributed_tensorflow_amd.compat import keras
     tf.reset_default_graph()
+    cluster._CURRENT_SERVER = None        # no task runtime in this process: the graph is only described, not trained
     setter = tf.train.replica_device_setter(worker_device="/job:worker/task:0",
                                             cluster={"ps": ["h:1", "h:2"], "worker": ["h:3"]})
     with tf.device(setter):
