@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd4_kernel(const float* __restri
 
 __global__ __launch_bounds__(256) void maxpool_bwd4_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ arg,
                                                            const float* __restrict__ x_relu, float* __restrict__ dx,
-                                                           const PoolGeom g, long long total) {
+                                                           const PoolGeom g, long long total, int mask_pooled) {
     const int CV = g.C / 4;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
         const int c = (int)(idx % CV) * 4;
@@ -208,10 +208,16 @@ __global__ __launch_bounds__(256) void maxpool_bwd4_kernel(const float* __restri
         }
         const long long dst = pix * g.C + c;
         if (x_relu) {
-            const f32x4 xr = *reinterpret_cast<const f32x4*>(x_relu + dst);
+            // the ReLU mask: from the full-resolution ReLU output, or (mask_pooled) from the POOLED tensor - at the
+            // arg-max position, the only one with a gradient, the two hold the same value
+            const bool inside = oh < g.OH && ow < g.OW;
+            const long long src = mask_pooled ? (inside ? (((long long)b * g.OH + oh) * g.OW + ow) * g.C + c : -1) : dst;
+            if (src >= 0) {
+                const f32x4 xr = *reinterpret_cast<const f32x4*>(x_relu + src);
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (!(xr[e] > 0.f)) r[e] = 0.f;
+                for (int e = 0; e < 4; ++e)
+                    if (!(xr[e] > 0.f)) r[e] = 0.f;
+            }
         }
         *reinterpret_cast<f32x4*>(dx + dst) = r;
     }
@@ -279,13 +285,14 @@ DTF_API int dtf_maxpool_fwd(const float* x, float* y, unsigned char* arg, int B,
 }
 
 DTF_API int dtf_maxpool_bwd(const float* dy, const unsigned char* arg, const float* x_relu, float* dx, int B, int H, int W,
-                            int C, int PH, int PW, hipStream_t stream) {
+                            int C, int PH, int PW, int mask_pooled, hipStream_t stream) {
     if (B <= 0 || H < PH || W < PW || C <= 0 || PH <= 0 || PW <= 0 || PH * PW > 255) return -3;
+    if (mask_pooled && x_relu && C % 4 != 0) return -3;
     const PoolGeom g = {B, H, W, C, PH, PW, H / PH, W / PW};
     const long long total = (long long)B * H * W * C;
     if (C % 4 == 0)
         hipLaunchKernelGGL(maxpool_bwd4_kernel, dim3(grid_for(total / 4)), dim3(256), 0, stream, dy, arg, x_relu, dx, g,
-                           total / 4);
+                           total / 4, mask_pooled);
     else
         hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, dy, arg, x_relu, dx, g, total);
     DTF_CHECK_LAUNCH();
@@ -341,6 +348,40 @@ __global__ __launch_bounds__(256) void conv_rowtab_kernel(int* __restrict__ rowt
     }
 }
 
+// Tables for gathering patches from an UNPADDED image: rowtab[m] = ((b*H + oh - pt)*W + (ow - pl)) * C, the origin of
+// the window of output pixel m = (b, oh, ow) - negative at the top / left border - and bit ky*KW + kx of masktab[m] set
+// iff input pixel (oh - pt + ky, ow - pl + kx) exists.  Taps outside the image then read as zero inside the GEMM loader,
+// and no zero-padded copy of the image is ever written.
+// pool_order: rows are numbered window by window of a 2x2 pooling over the output, m = ((b*OH/2 + py)*OW/2 + px)*4 +
+// 2*dy + dx for output pixel (2py + dy, 2px + dx), so that four consecutive GEMM rows are one pooling window.
+__global__ __launch_bounds__(256) void conv_rowtab_masked_kernel(int* __restrict__ rowtab, unsigned* __restrict__ masktab, int B,
+                                                                 int OH, int OW, int H, int W, int KH, int KW, int pt, int pl,
+                                                                 int C, int pool_order, long long total) {
+    for (long long m = (long long)blockIdx.x * 256 + threadIdx.x; m < total; m += (long long)gridDim.x * 256) {
+        int ow, oh, b;
+        if (pool_order) {
+            const int pos = (int)(m & 3);
+            const long long win = m >> 2;
+            const int PW2 = OW / 2, PH2 = OH / 2;
+            ow = (int)(win % PW2) * 2 + (pos & 1);
+            oh = (int)((win / PW2) % PH2) * 2 + (pos >> 1);
+            b = (int)(win / ((long long)PW2 * PH2));
+        } else {
+            ow = (int)(m % OW);
+            oh = (int)((m / OW) % OH);
+            b = (int)(m / ((long long)OW * OH));
+        }
+        rowtab[m] = (int)((((long long)b * H + (oh - pt)) * W + (ow - pl)) * C);
+        unsigned mk = 0;
+        for (int ky = 0; ky < KH; ++ky)
+            for (int kx = 0; kx < KW; ++kx) {
+                const int h = oh - pt + ky, w = ow - pl + kx;
+                if (h >= 0 && h < H && w >= 0 && w < W) mk |= 1u << (ky * KW + kx);
+            }
+        masktab[m] = mk;
+    }
+}
+
 // wflip[((KH-1-kh)*KW + (KW-1-kw))*N + n][c] = w[kh][kw][c][n]
 __global__ __launch_bounds__(256) void conv_flip_kernel(const float* __restrict__ w, float* __restrict__ wflip, int KH, int KW,
                                                         int C, int N, int total) {
@@ -367,6 +408,18 @@ DTF_API int dtf_conv_pad(const float* src, float* dst, int B, int H, int W, int 
     }
     const long long total = (long long)B * Hp * Wp * (C / 4);
     hipLaunchKernelGGL(pad_nhwc_kernel, dim3(grid_for(total)), dim3(256), 0, stream, src, dst, B, H, W, C, pt, pl, Hp, Wp, total);
+    DTF_CHECK_LAUNCH();
+    return 0;
+}
+
+DTF_API int dtf_conv_rowtab_masked(int* rowtab, unsigned* masktab, int B, int OH, int OW, int H, int W, int KH, int KW, int pt,
+                                   int pl, int C, int pool_order, hipStream_t stream) {
+    if (B <= 0 || OH <= 0 || OW <= 0 || H <= 0 || W <= 0 || C <= 0 || KH <= 0 || KW <= 0 || KH * KW > 32) return -3;
+    if (pool_order && (OH % 2 != 0 || OW % 2 != 0)) return -3;
+    if ((long long)B * H * W * C >= (1ll << 30)) return -8;      // byte offsets of the gather are 32-bit
+    const long long total = (long long)B * OH * OW;
+    hipLaunchKernelGGL(conv_rowtab_masked_kernel, dim3(grid_for(total)), dim3(256), 0, stream, rowtab, masktab, B, OH, OW, H, W,
+                       KH, KW, pt, pl, C, pool_order, total);
     DTF_CHECK_LAUNCH();
     return 0;
 }

@@ -62,6 +62,9 @@ struct GemmArgs {
     float keep;               // dropout keep probability; >= 1 disables dropout
     uint32_t seed;
     const long long* step_ptr;
+    unsigned char* pool_arg;  // forward, rows ordered four-per-2x2-pooling-window (see conv_rowtab_masked_kernel): C is the
+                              // POOLED output [M/4, N] and pool_arg[M/4, N] receives the arg-max position 0..3 of every
+                              // window; the full-resolution activation is never written.  Null: plain forward.
     // dgrad epilogue
     const float* yprev;       // output of the producing layer (post activation/dropout)
     int ldy;
@@ -74,6 +77,10 @@ struct GemmArgs {
     // never materialised.  Patch row m starts at element g_rowtab[m] of the image; window position w = k / g_C
     // adds g_shift[w]; the channel k % g_C is contiguous.
     const int* g_rowtab;      // [g_rows]
+    const unsigned* g_masktab; // [g_rows] or null.  Null: the image is zero-padded and every tap of every row is inside it.
+                              // Otherwise the image is NOT padded: bit w of g_masktab[m] tells whether window position w
+                              // of patch row m lies inside the image (taps outside read as zero), and g_rowtab[m] - the
+                              // origin of the window - may be negative for rows at the image border.
     const int* g_shift;       // [KH*KW]
     int g_rows;
     int g_C;                  // channels per window position (multiple of 32 for k-contiguous A, of 4 otherwise)
@@ -336,7 +343,8 @@ struct GatherLoader<ROWS, true> {
     __amdgpu_buffer_rsrc_t rsrc;
     const int* shift;
     int C;
-    int rb[NV];     // image offset of this thread's patch rows (-1: row past M)
+    int rb[NV];          // image offset of this thread's patch rows
+    unsigned taps[NV];   // bit w: window position w of the row is inside the image (0: row past M)
     f32x4 v[NV];
 
     __device__ __forceinline__ void init_gather(const GemmArgs& p, int mn0, int kbeg, int tid) {
@@ -344,19 +352,22 @@ struct GatherLoader<ROWS, true> {
         shift = p.g_shift;
         C = p.g_C;
         __amdgpu_buffer_rsrc_t tab = make_rsrc(reinterpret_cast<const float*>(p.g_rowtab), (long long)p.g_rows * 4);
+        __amdgpu_buffer_rsrc_t mtab = make_rsrc(reinterpret_cast<const float*>(p.g_masktab), p.g_masktab ? (long long)p.g_rows * 4 : 0);
 #pragma unroll
         for (int s = 0; s < NV; ++s) {
             const int m = mn0 + ((tid + 256 * s) >> 3);
-            const int t = (int)__builtin_amdgcn_raw_buffer_load_b32(tab, m * 4, 0, 0);
-            rb[s] = (m < p.M) ? t : -1;
+            rb[s] = (int)__builtin_amdgcn_raw_buffer_load_b32(tab, m * 4, 0, 0);
+            const unsigned mk = p.g_masktab ? __builtin_amdgcn_raw_buffer_load_b32(mtab, m * 4, 0, 0) : 0xFFFFFFFFu;
+            taps[s] = (m < p.M) ? mk : 0u;
         }
     }
     __device__ __forceinline__ void load(int k0, int kbeg, int k_left, int tid) {
-        const int sh = shift[k0 / C] + (k0 % C);        // uniform: a 32-deep k tile lies inside one window position
+        const int w = k0 / C;                           // uniform: a 32-deep k tile lies inside one window position
+        const int sh = shift[w] + (k0 % C);
 #pragma unroll
         for (int s = 0; s < NV; ++s) {
             const int c = ((tid + 256 * s) & 7) * 4;
-            const bool ok = (rb[s] >= 0) && (c < k_left);
+            const bool ok = ((taps[s] >> w) & 1u) && (c < k_left);
             const unsigned off = (unsigned)(rb[s] + sh + c) * 4u;
             const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(ok ? off : OOB), 0, 0);
             v[s] = __builtin_bit_cast(f32x4, raw);
@@ -376,34 +387,44 @@ template <int ROWS>
 struct GatherLoader<ROWS, false> {
     static constexpr int NV = ROWS * BK / 4 / 256;
     static constexpr int LDS_FLOATS = BK * (ROWS + 4);
-    __amdgpu_buffer_rsrc_t rsrc, tab;
+    __amdgpu_buffer_rsrc_t rsrc, tab, mtab;
     int ko[NV];       // image offset of this thread's patch columns relative to the row origin (-1: past the patch)
+    int wpos[NV];     // window position of those columns
     int rb_next[NV];  // row origin of the NEXT tile's patch row, requested one tile ahead
+    unsigned mk_next[NV];   // and which of its window positions are inside the image
+    bool masked;
     f32x4 v[NV];
 
     __device__ __forceinline__ void init_gather(const GemmArgs& p, int mn0, int kbeg, int tid) {
         rsrc = make_rsrc(p.A, p.g_elems * 4);
         tab = make_rsrc(reinterpret_cast<const float*>(p.g_rowtab), (long long)p.g_rows * 4);
+        masked = p.g_masktab != nullptr;
+        mtab = make_rsrc(reinterpret_cast<const float*>(p.g_masktab), masked ? (long long)p.g_rows * 4 : 0);
 #pragma unroll
         for (int s = 0; s < NV; ++s) {
             const int id = tid + 256 * s;
             const int kin = mn0 + (id % (ROWS / 4)) * 4;
-            ko[s] = (kin < p.M) ? p.g_shift[kin / p.g_C] + kin % p.g_C : -1;
+            wpos[s] = (kin < p.M) ? kin / p.g_C : 0;
+            ko[s] = (kin < p.M) ? p.g_shift[wpos[s]] + kin % p.g_C : -1;
             rb_next[s] = (int)__builtin_amdgcn_raw_buffer_load_b32(tab, (kbeg + id / (ROWS / 4)) * 4, 0, 0);
+            mk_next[s] = masked ? __builtin_amdgcn_raw_buffer_load_b32(mtab, (kbeg + id / (ROWS / 4)) * 4, 0, 0) : 0xFFFFFFFFu;
         }
     }
     __device__ __forceinline__ void load(int k0, int kbeg, int k_left, int tid) {
 #pragma unroll
         for (int s = 0; s < NV; ++s) {
             const int c = (tid + 256 * s) / (ROWS / 4);
-            const bool ok = (ko[s] >= 0) && (c < k_left);
+            const bool ok = (ko[s] >= 0) && (c < k_left) && ((mk_next[s] >> wpos[s]) & 1u);
             const unsigned off = (unsigned)(rb_next[s] + ko[s]) * 4u;
             const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(ok ? off : OOB), 0, 0);
             v[s] = __builtin_bit_cast(f32x4, raw);
         }
 #pragma unroll
-        for (int s = 0; s < NV; ++s)      // past the table the load returns 0 and the data load is masked by k_left
-            rb_next[s] = (int)__builtin_amdgcn_raw_buffer_load_b32(tab, (k0 + BK + (tid + 256 * s) / (ROWS / 4)) * 4, 0, 0);
+        for (int s = 0; s < NV; ++s) {    // past the table the loads return 0 and the data load is masked by k_left
+            const int row = (k0 + BK + (tid + 256 * s) / (ROWS / 4)) * 4;
+            rb_next[s] = (int)__builtin_amdgcn_raw_buffer_load_b32(tab, row, 0, 0);
+            if (masked) mk_next[s] = __builtin_amdgcn_raw_buffer_load_b32(mtab, row, 0, 0);
+        }
     }
     __device__ __forceinline__ void store(float* lds, int k_left, int tid) const {
 #pragma unroll
@@ -441,6 +462,38 @@ template <int TM, int TN, int BM, int BN, int EPI>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int li,
                                               int h) {
     float* C = p.C + (long long)blockIdx.z * p.c_split_stride;
+    if (EPI == EPI_FWD && p.pool_arg) {
+        // 2x2 max pooling in registers: in the C/D layout of the 32x32 MFMA the four registers 4q..4q+3 of a lane are
+        // four CONSECUTIVE rows, and the row order of the patch table makes those the four pixels of one pooling
+        // window - bias, ReLU, max and arg-max never leave the lane (first maximum wins, like the stand-alone kernel).
+        const float floor_v = (p.act == ACT_RELU) ? 0.f : -INFINITY;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + (wn * TN + j) * 32 + li;
+                if (col >= p.N) continue;
+                const float bv = p.bias ? p.bias[col] : 0.f;
+                const int row0 = m0 + (wm * TM + i) * 32 + 4 * h;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int row = row0 + 8 * q;
+                    if (row >= p.M) continue;
+                    float best = fmaxf(acc[i][j][4 * q] + bv, floor_v);
+                    int bi = 0;
+#pragma unroll
+                    for (int k = 1; k < 4; ++k) {
+                        const float v = fmaxf(acc[i][j][4 * q + k] + bv, floor_v);
+                        if (v > best) { best = v; bi = k; }
+                    }
+                    const long long o = (long long)(row >> 2) * p.ldc + col;
+                    C[o] = best;
+                    p.pool_arg[o] = (unsigned char)bi;
+                }
+            }
+        }
+        return;
+    }
     uint32_t key = 0;
     const bool drop = (EPI == EPI_FWD) && (p.keep < 1.0f);
     float inv_keep = 1.0f;
@@ -1258,14 +1311,16 @@ static bool gather_ok(const int* rowtab, const int* shift, int C, int K, bool a_
 // Y[M,N] = act(patches(Xpad)[M,K] . W[K,N] + b), K = KH*KW*C
 DTF_API int dtf_conv_gemm_fwd(const float* Xpad, long long xpad_elems, const int* rowtab, const int* shift, int C,
                               const float* W, const float* bias, float* Y, int M, int N, int K, int act,
-                              hipStream_t stream) {
+                              const unsigned* masktab, unsigned char* pool_arg, hipStream_t stream) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     if (!gather_ok(rowtab, shift, C, K, true)) return -3;
+    if (pool_arg && (M % 4 != 0 || (act != ACT_NONE && act != ACT_RELU))) return -3;
     GemmArgs a = {};
     a.A = Xpad; a.lda = 0; a.B = W; a.ldb = N; a.C = Y; a.ldc = N;
     a.M = M; a.N = N; a.K = K; a.k_chunk = K;
     a.bias = bias; a.act = act; a.keep = 1.0f;
-    a.g_rowtab = rowtab; a.g_shift = shift; a.g_rows = M; a.g_C = C; a.g_elems = xpad_elems;
+    a.g_rowtab = rowtab; a.g_shift = shift; a.g_rows = M; a.g_C = C; a.g_elems = xpad_elems; a.g_masktab = masktab;
+    a.pool_arg = pool_arg;
     return launch_gather<true, false, EPI_FWD>(a, 1, stream);
 }
 
@@ -1274,21 +1329,21 @@ DTF_API int dtf_conv_gemm_fwd(const float* Xpad, long long xpad_elems, const int
 // K = KH*KW*Cout, N = Cin.
 DTF_API int dtf_conv_gemm_dgrad(const float* dZpad, long long dzpad_elems, const int* rowtab, const int* shift, int Cout,
                                 const float* Wflip, float* dX, int M, int N, int K, const float* Yprev, int act_prev,
-                                hipStream_t stream) {
+                                const unsigned* masktab, hipStream_t stream) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     if (!gather_ok(rowtab, shift, Cout, K, true)) return -3;
     GemmArgs a = {};
     a.A = dZpad; a.B = Wflip; a.ldb = N; a.C = dX; a.ldc = N;
     a.M = M; a.N = N; a.K = K; a.k_chunk = K;
     a.yprev = Yprev; a.ldy = N; a.act = act_prev; a.scale_prev = 1.0f;
-    a.g_rowtab = rowtab; a.g_shift = shift; a.g_rows = M; a.g_C = Cout; a.g_elems = dzpad_elems;
+    a.g_rowtab = rowtab; a.g_shift = shift; a.g_rows = M; a.g_C = Cout; a.g_elems = dzpad_elems; a.g_masktab = masktab;
     return launch_gather<true, false, EPI_DX>(a, 1, stream);
 }
 
 // dW[K,N] = patches(Xpad)[M,K]^T . dZ[M,N], db = colsum(dZ); workspace as for dtf_dense_bwd_dw(M, N, K)
 DTF_API int dtf_conv_gemm_wgrad(const float* Xpad, long long xpad_elems, const int* rowtab, const int* shift, int C,
                                 const float* dZ, float* dW, float* db, int M, int N, int K, float* workspace,
-                                hipStream_t stream) {
+                                const unsigned* masktab, hipStream_t stream) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     if (!gather_ok(rowtab, shift, C, K, false)) return -3;
     const int splits = dtf_dense_bwd_dw_splits(M, N, K);
@@ -1296,7 +1351,7 @@ DTF_API int dtf_conv_gemm_wgrad(const float* Xpad, long long xpad_elems, const i
     GemmArgs a = {};
     a.A = Xpad; a.B = dZ; a.ldb = N;
     a.M = K; a.N = N; a.K = M; a.ldc = N;
-    a.g_rowtab = rowtab; a.g_shift = shift; a.g_rows = M; a.g_C = C; a.g_elems = xpad_elems;
+    a.g_rowtab = rowtab; a.g_shift = shift; a.g_rows = M; a.g_C = C; a.g_elems = xpad_elems; a.g_masktab = masktab;
     int chunk = (M + splits - 1) / splits;
     chunk = ((chunk + BK - 1) / BK) * BK;
     a.k_chunk = chunk;

@@ -324,7 +324,8 @@ class Conv2D(Layer):
         self.bias = None
         self.fuse_prev_relu = False      # producing layer's ReLU gradient folded into this layer's col2im
         self.fused_pool = None           # the 2x2 MaxPooling2D that follows, when the pair may run as one kernel
-        self._fused_ran = False
+        self._fused_ran = False          # ran as the first-layer conv+pool kernel
+        self._gemm_pool_ran = False      # ran as the implicit GEMM with the pooling in its epilogue
         self._buf = _Buffers()
         self._ws = None
         self._x = self._y = self._cols = None
@@ -379,13 +380,30 @@ class Conv2D(Layer):
             kh, kw = self.kernel_size
             OH, OW, pt, pl, pb, pr = F.conv_geometry(H, W, kh, kw, self.strides, self.padding)
             Hp, Wp = H + pt + pb, W + pl + pr
-            g = {"pt": pt, "pl": pl, "Hp": Hp, "Wp": Wp, "xpad": torch.empty((B, Hp, Wp, C), dtype=torch.float32, device=x.device)}
-            g["rowtab"], g["shift"] = F.conv_tables(B, OH, OW, Hp, Wp, kh, kw, C, x.device)
+            # windows of up to 32 positions: patches are gathered straight from the activations as they are stored and a
+            # per-pixel bit set tells the loader which taps fall outside the image - no zero-padded copy is written
+            # (for the MNIST CNN that removes three memory-bound passes per step); larger windows go through a copy
+            g = {"pt": pt, "pl": pl, "Hp": Hp, "Wp": Wp, "masked": kh * kw <= 32}
+            if g["masked"]:
+                g["rowtab"], g["shift"], g["mask"] = F.conv_tables_unpadded(B, OH, OW, H, W, kh, kw, pt, pl, C, x.device)
+                if self._pool_in_epilogue_ok(OH, OW):
+                    # same patches, numbered pooling window by pooling window: the forward GEMM pools in its epilogue
+                    g["rowtab_pool"], _, g["mask_pool"] = F.conv_tables_unpadded(B, OH, OW, H, W, kh, kw, pt, pl, C,
+                                                                                 x.device, pool_order=True)
+            else:
+                g["xpad"] = torch.empty((B, Hp, Wp, C), dtype=torch.float32, device=x.device)
+                g["rowtab"], g["shift"] = F.conv_tables(B, OH, OW, Hp, Wp, kh, kw, C, x.device)
+                g["mask"] = None
             if self.need_input_grad:
                 N = self.filters
                 g["top"], g["left"], g["Hq"], g["Wq"] = kh - 1 - pt, kw - 1 - pl, H + kh - 1, W + kw - 1
-                g["dzpad"] = torch.empty((B, g["Hq"], g["Wq"], N), dtype=torch.float32, device=x.device)
-                g["rowtab_d"], g["shift_d"] = F.conv_tables(B, H, W, g["Hq"], g["Wq"], kh, kw, N, x.device)
+                if g["masked"]:
+                    g["rowtab_d"], g["shift_d"], g["mask_d"] = F.conv_tables_unpadded(B, H, W, OH, OW, kh, kw, g["top"],
+                                                                                      g["left"], N, x.device)
+                else:
+                    g["dzpad"] = torch.empty((B, g["Hq"], g["Wq"], N), dtype=torch.float32, device=x.device)
+                    g["rowtab_d"], g["shift_d"] = F.conv_tables(B, H, W, g["Hq"], g["Wq"], kh, kw, N, x.device)
+                    g["mask_d"] = None
                 g["wflip"] = torch.empty((kh * kw * N, C), dtype=torch.float32, device=x.device)
             self._geo[key] = g
         return g
@@ -411,18 +429,39 @@ class Conv2D(Layer):
             self._x, self._cols, self._y = xin, None, ypool
             pool._x, pool._arg = None, arg
             return ypool
-        y = self._buf.get("y", (B * OH * OW, Fo), x.device)
         self._used_implicit = self._implicit(x)
+        self._gemm_pool_ran = False
         if self._used_implicit:
             g = self._geometry(x)
-            F.conv_pad(x, g["pt"], g["pl"], g["Hp"], g["Wp"], out=g["xpad"])
-            F.conv_gemm_forward(g["xpad"], g["rowtab"], g["shift"], self.kernel.tensor.view(-1, Fo), bias, self.act, y)
+            if "rowtab_pool" in g:
+                # convolution + bias + ReLU + 2x2 max pooling in one GEMM: only the pooled tensor and the arg-max
+                # leave the chip (the full-resolution activation, four times the size, is never written)
+                pool = self.fused_pool
+                shape = (B, OH // 2, OW // 2, Fo)
+                ypool = pool._buf.get("y", shape, x.device)
+                arg = pool._arg_buffer(shape, x.device)
+                F.conv_gemm_forward(x, g["rowtab_pool"], g["shift"], self.kernel.tensor.view(-1, Fo), bias, self.act,
+                                    ypool.view(-1, Fo), masktab=g["mask_pool"], pool_arg=arg)
+                self._x, self._cols, self._y = x, None, None
+                pool._x, pool._arg, pool._ypool = None, arg, ypool
+                self._gemm_pool_ran = True
+                return ypool
+        y = self._buf.get("y", (B * OH * OW, Fo), x.device)
+        if self._used_implicit:
+            src = x if g["masked"] else F.conv_pad(x, g["pt"], g["pl"], g["Hp"], g["Wp"], out=g["xpad"])
+            F.conv_gemm_forward(src, g["rowtab"], g["shift"], self.kernel.tensor.view(-1, Fo), bias, self.act, y,
+                                masktab=g["mask"])
             cols = None
         else:
             cols = self._patches(x)
             F.dense_forward(cols, self.kernel.tensor.view(-1, Fo), bias, self.act, out=y)
         self._x, self._cols, self._y = x, cols, y
         return y.view(B, OH, OW, Fo)
+
+    def _pool_in_epilogue_ok(self, OH: int, OW: int) -> bool:
+        """May the 2x2 pooling that follows run in the epilogue of this layer's implicit GEMM?"""
+        return (self.fused_pool is not None and OH % 2 == 0 and OW % 2 == 0 and self.filters % 4 == 0
+                and self.act in (ACT_NONE, ACT_RELU) and (self.grad_is_dz or self.act == ACT_NONE))
 
     def _fusable_with_pool(self, x) -> bool:
         return (self.fused_pool is not None and x.is_cuda and not self.need_input_grad and self.act in (ACT_NONE, ACT_RELU)
@@ -455,7 +494,8 @@ class Conv2D(Layer):
         if self._fused_ran:
             return self._backward_fused_pool(dy)
         x, cols, y = self._x, self._cols, self._y
-        M, Fo = y.shape
+        OHo, OWo, Fo = self.output_shape
+        M = x.shape[0] * OHo * OWo
         kh, kw = self.kernel_size
         K = kh * kw * x.shape[3]
         dy2 = dy.reshape(M, Fo)
@@ -473,16 +513,18 @@ class Conv2D(Layer):
         db = self.bias.grad if self.bias is not None else None
         if self._used_implicit:
             g = self._geometry(x)
-            F.conv_gemm_wgrad(g["xpad"], g["rowtab"], g["shift"], dz, dw2d, db, self._ws[1])
+            F.conv_gemm_wgrad(x if g["masked"] else g["xpad"], g["rowtab"], g["shift"], dz, dw2d, db, self._ws[1],
+                              masktab=g["mask"])
             if not self.need_input_grad:
                 return None
             B, H, W, C = x.shape
             OH, OW, _ = self.output_shape
-            F.conv_pad(dz.view(B, OH, OW, Fo), g["top"], g["left"], g["Hq"], g["Wq"], out=g["dzpad"])
+            dz4 = dz.view(B, OH, OW, Fo)
+            dsrc = dz4 if g["masked"] else F.conv_pad(dz4, g["top"], g["left"], g["Hq"], g["Wq"], out=g["dzpad"])
             F.conv_flip_weights(self.kernel.tensor, out=g["wflip"])
             dx = self._buf.get("dx", (B * H * W, C), x.device)
-            F.conv_gemm_dgrad(g["dzpad"], g["rowtab_d"], g["shift_d"], g["wflip"], dx,
-                              yprev=x.view(-1, C) if self.fuse_prev_relu else None)
+            F.conv_gemm_dgrad(dsrc, g["rowtab_d"], g["shift_d"], g["wflip"], dx,
+                              yprev=x.view(-1, C) if self.fuse_prev_relu else None, masktab=g["mask_d"])
             return dx.view(x.shape)
         F.dense_backward_dw(cols, dz, dw2d, db, workspace=self._ws[1])
         if not self.need_input_grad:
@@ -538,7 +580,7 @@ class MaxPooling2D(Layer):
         return arg
 
     def forward(self, x, training):
-        if self.fused_into is not None and self.fused_into._fused_ran:
+        if self.fused_into is not None and (self.fused_into._fused_ran or self.fused_into._gemm_pool_ran):
             return x                     # already pooled by the convolution's kernel
         x = x.contiguous()
         B = x.shape[0]
@@ -552,6 +594,14 @@ class MaxPooling2D(Layer):
     def backward(self, dy):
         if self.fused_into is not None and self.fused_into._fused_ran:
             return dy                    # the convolution's wgrad kernel consumes the pooled gradient
+        if self.fused_into is not None and self.fused_into._gemm_pool_ran:
+            # pooled in the convolution's GEMM epilogue: the full-resolution activation was never stored; the ReLU
+            # mask comes from the pooled tensor (equal to it at the arg-max, the only position with a gradient)
+            conv = self.fused_into
+            shape = (dy.shape[0],) + tuple(conv.output_shape)
+            dx = self._buf.get("dx", shape, dy.device)
+            return F.maxpool_backward(dy.contiguous(), self._arg, shape, self.pool_size,
+                                      self._ypool if self.fold_relu_grad else None, out=dx, mask_pooled=True)
         x = self._x
         dx = self._buf.get("dx", x.shape, x.device)
         return F.maxpool_backward(dy.contiguous(), self._arg, x.shape, self.pool_size,

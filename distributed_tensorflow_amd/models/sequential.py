@@ -139,15 +139,17 @@ class Sequential:
             elif isinstance(a, Conv2D) and a.act == ACT_RELU and isinstance(b, MaxPooling2D):
                 b.fold_relu_grad = True          # pooling backward also applies the conv's ReLU gradient
                 a.grad_is_dz = True
+            if isinstance(a, Conv2D) and isinstance(b, MaxPooling2D) and b.pool_size == (2, 2) \
+                    and a.act in (ACT_NONE, ACT_RELU):
+                # the pair may run with the pooling inside the convolution's kernel (decided per call: GPU, shape):
+                # the first-layer kernel of conv_pool.hip, or the pooling epilogue of the implicit-GEMM convolution
+                a.fused_pool = b
+                b.fused_into = a
             elif isinstance(a, Conv2D) and a.act == ACT_RELU and isinstance(b, Conv2D):
                 b.fuse_prev_relu = True          # col2im (or the 1x1 dgrad epilogue) applies it
                 a.grad_is_dz = True
         if eff:
             eff[0].need_input_grad = False
-        # a first-layer convolution followed by 2x2 pooling may run as one kernel (decided per call: GPU, shape)
-        if len(eff) > 1 and isinstance(eff[0], Conv2D) and isinstance(eff[1], MaxPooling2D) and eff[1].pool_size == (2, 2):
-            eff[0].fused_pool = eff[1]
-            eff[1].fused_into = eff[0]
         self._effective = eff
 
     # ------------------------------------------------------------------ compile

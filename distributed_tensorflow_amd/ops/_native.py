@@ -82,13 +82,14 @@ def kernels():
         "dtf_conv_pool_workspace_floats": [c_i] * 4,
         "dtf_conv_pool_fwd": [c_p] * 5 + [c_i] * 12 + [c_p],
         "dtf_conv_pool_wgrad": [c_p] * 6 + [c_i] * 12 + [c_p, c_p],
-        "dtf_maxpool_bwd": [c_p, c_p, c_p, c_p] + [c_i] * 6 + [c_p],
+        "dtf_maxpool_bwd": [c_p, c_p, c_p, c_p] + [c_i] * 7 + [c_p],
         "dtf_conv_pad": [c_p, c_p] + [c_i] * 8 + [c_p],
         "dtf_conv_rowtab": [c_p] + [c_i] * 6 + [c_p],
         "dtf_conv_flip_weights": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
-        "dtf_conv_gemm_fwd": [c_p, c_ll, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
-        "dtf_conv_gemm_dgrad": [c_p, c_ll, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_p],
-        "dtf_conv_gemm_wgrad": [c_p, c_ll, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p],
+        "dtf_conv_rowtab_masked": [c_p, c_p] + [c_i] * 11 + [c_p],
+        "dtf_conv_gemm_fwd": [c_p, c_ll, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p],
+        "dtf_conv_gemm_dgrad": [c_p, c_ll, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p],
+        "dtf_conv_gemm_wgrad": [c_p, c_ll, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p],
         "dtf_mlp_tail_supported": [c_i, c_i, c_i],
         "dtf_mlp_tail": [c_p] * 12 + [c_ll, c_i, c_i, c_i, c_i, c_f, c_u32, c_p, c_f, c_f, c_p, c_p],
         "dtf_mlp3_fused_supported": [c_i, c_i, c_i, c_i, c_i],

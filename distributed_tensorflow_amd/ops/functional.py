@@ -603,9 +603,9 @@ def conv_pool_wgrad(x, dpool, ypool, arg, dw2d, db, act, KH, KW, padding, worksp
     nv.check(rc, "dtf_conv_pool_wgrad")
 
 
-def maxpool_backward(dy, arg, x_shape, pool=(2, 2), x_relu=None, out=None):
-    """Route ``dy`` to each window's arg-max position; ``x_relu`` (the pooled tensor, a ReLU output) folds the ReLU
-    gradient in."""
+def maxpool_backward(dy, arg, x_shape, pool=(2, 2), x_relu=None, out=None, mask_pooled=False):
+    """Route ``dy`` to each window's arg-max position; ``x_relu`` folds the gradient of the ReLU in front of the pooling
+    in: the pooling's full-resolution input, or - ``mask_pooled`` - its pooled OUTPUT (same value at the arg-max)."""
     B, H, W, C = x_shape
     PH, PW = pool
     OH, OW = H // PH, W // PW
@@ -614,7 +614,7 @@ def maxpool_backward(dy, arg, x_shape, pool=(2, 2), x_relu=None, out=None):
     if dy.is_cuda:
         nv.require_f32_contig(dy, out, x_relu)
         rc = nv.kernels().dtf_maxpool_bwd(nv.ptr(dy), nv.ptr(arg), nv.ptr(x_relu), nv.ptr(out), B, H, W, C, PH, PW,
-                                          nv.stream_ptr())
+                                          int(mask_pooled), nv.stream_ptr())
         nv.check(rc, "dtf_maxpool_bwd")
         return out
     onehot = torch.nn.functional.one_hot(arg.to(torch.int64), PH * PW).to(dy.dtype) * dy.unsqueeze(-1)   # [B,OH,OW,C,P]
@@ -622,7 +622,11 @@ def maxpool_backward(dy, arg, x_shape, pool=(2, 2), x_relu=None, out=None):
     out.zero_()
     out[:, :OH * PH, :OW * PW, :] = g
     if x_relu is not None:
-        out.mul_((x_relu > 0).to(out.dtype))
+        if mask_pooled:
+            keep = (x_relu > 0).to(out.dtype).repeat_interleave(PH, dim=1).repeat_interleave(PW, dim=2)
+            out[:, :OH * PH, :OW * PW, :].mul_(keep)
+        else:
+            out.mul_((x_relu > 0).to(out.dtype))
     return out
 
 
@@ -695,6 +699,23 @@ def conv_tables(B: int, OH: int, OW: int, Hp: int, Wp: int, KH: int, KW: int, C:
     return rowtab, shift
 
 
+def conv_tables_unpadded(B: int, OH: int, OW: int, H: int, W: int, KH: int, KW: int, pt: int, pl: int, C: int, device,
+                         pool_order: bool = False):
+    """``(rowtab, shift, masktab)`` for gathering patches from an image that is NOT zero-padded: window origins (negative
+    at the top / left border), window-position offsets, and per output pixel the bit set of window positions that lie
+    inside the image (the GEMM loader reads the others as zero).  Needs ``KH * KW <= 32``.  ``pool_order`` numbers the
+    output pixels window by window of a 2x2 pooling (four consecutive rows = one window; even ``OH``, ``OW``)."""
+    rowtab = torch.empty(B * OH * OW, dtype=torch.int32, device=device)
+    masktab = torch.empty(B * OH * OW, dtype=torch.int32, device=device)
+    rc = nv.kernels().dtf_conv_rowtab_masked(nv.ptr(rowtab), nv.ptr(masktab), B, OH, OW, H, W, KH, KW, pt, pl, C,
+                                             int(pool_order), nv.stream_ptr())
+    nv.check(rc, "dtf_conv_rowtab_masked")
+    kh = torch.arange(KH, dtype=torch.int32).view(KH, 1)
+    kw = torch.arange(KW, dtype=torch.int32).view(1, KW)
+    shift = ((kh * W + kw) * C).reshape(-1).contiguous().to(device)
+    return rowtab, shift, masktab
+
+
 def conv_flip_weights(w, out=None):
     """``[KH, KW, C, N]`` filter -> ``[(KH*KW*N), C]`` matrix of the data-gradient convolution (spatially flipped,
     channels transposed)."""
@@ -707,19 +728,22 @@ def conv_flip_weights(w, out=None):
     return out
 
 
-def conv_gemm_forward(xpad, rowtab, shift, w2d, bias, act, out):
-    """``out[M, N] = act(patches(xpad) @ w2d + bias)`` with the patches gathered inside the GEMM."""
+def conv_gemm_forward(xpad, rowtab, shift, w2d, bias, act, out, masktab=None, pool_arg=None):
+    """``out[M, N] = act(patches(xpad) @ w2d + bias)`` with the patches gathered inside the GEMM (``masktab``: the image
+    is not padded, see ``conv_tables_unpadded``).  With ``pool_arg`` (uint8 ``[M/4, N]``) and pool-ordered tables,
+    ``out`` is the 2x2-max-pooled result ``[M/4, N]`` and ``pool_arg`` its arg-max positions."""
     K, N = w2d.shape
     M = rowtab.numel()
     C = xpad.shape[-1]
     nv.require_f32_contig(xpad, w2d, bias, out)
     rc = nv.kernels().dtf_conv_gemm_fwd(nv.ptr(xpad), xpad.numel(), nv.ptr(rowtab), nv.ptr(shift), C, nv.ptr(w2d), nv.ptr(bias),
-                                        nv.ptr(out), M, N, K, int(act), nv.stream_ptr())
+                                        nv.ptr(out), M, N, K, int(act), nv.ptr(masktab), nv.ptr(pool_arg),
+                                        nv.stream_ptr())
     nv.check(rc, "dtf_conv_gemm_fwd")
     return out
 
 
-def conv_gemm_wgrad(xpad, rowtab, shift, dz, dw2d, db, workspace):
+def conv_gemm_wgrad(xpad, rowtab, shift, dz, dw2d, db, workspace, masktab=None):
     """``dw2d[K, N] = patches(xpad)^T @ dz``, ``db = colsum(dz)``."""
     K, N = dw2d.shape
     M = rowtab.numel()
@@ -728,17 +752,17 @@ def conv_gemm_wgrad(xpad, rowtab, shift, dz, dw2d, db, workspace):
     if workspace is None or workspace.numel() < max(need, 1):
         raise ValueError("conv wgrad workspace needs %d floats" % need)
     rc = nv.kernels().dtf_conv_gemm_wgrad(nv.ptr(xpad), xpad.numel(), nv.ptr(rowtab), nv.ptr(shift), xpad.shape[-1], nv.ptr(dz),
-                                          nv.ptr(dw2d), nv.ptr(db), M, N, K, nv.ptr(workspace), nv.stream_ptr())
+                                          nv.ptr(dw2d), nv.ptr(db), M, N, K, nv.ptr(workspace), nv.ptr(masktab), nv.stream_ptr())
     nv.check(rc, "dtf_conv_gemm_wgrad")
 
 
-def conv_gemm_dgrad(dzpad, rowtab, shift, wflip, dx, yprev=None):
+def conv_gemm_dgrad(dzpad, rowtab, shift, wflip, dx, yprev=None, masktab=None):
     """``dx[M, C] = patches(dzpad) @ wflip`` (optionally times the ReLU gradient of ``yprev``)."""
     K, C = wflip.shape
     M = rowtab.numel()
     nv.require_f32_contig(dzpad, wflip, dx, yprev)
     rc = nv.kernels().dtf_conv_gemm_dgrad(nv.ptr(dzpad), dzpad.numel(), nv.ptr(rowtab), nv.ptr(shift), dzpad.shape[-1],
                                           nv.ptr(wflip), nv.ptr(dx), M, C, K, nv.ptr(yprev),
-                                          ACT_RELU if yprev is not None else ACT_NONE, nv.stream_ptr())
+                                          ACT_RELU if yprev is not None else ACT_NONE, nv.ptr(masktab), nv.stream_ptr())
     nv.check(rc, "dtf_conv_gemm_dgrad")
     return dx

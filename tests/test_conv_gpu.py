@@ -164,3 +164,58 @@ def test_cnn_with_implicit_convs_matches_autograd(gpu_device):
     assert m.read_stats()["loss"] == pytest.approx(ref_loss, rel=1e-4)
     for v, p in zip(m.store.trainable, params):
         torch.testing.assert_close(v.grad.cpu(), p.grad, rtol=2e-3, atol=2e-5, msg=v.name)
+
+
+@pytest.mark.parametrize("g", [
+    dict(B=4, H=14, W=14, C=32, N=64, KH=5, KW=5, padding="same"),
+    dict(B=3, H=10, W=12, C=64, N=32, KH=3, KW=3, padding="valid"),
+    dict(B=2, H=8, W=8, C=32, N=96, KH=2, KW=3, padding="same"),
+])
+def test_unpadded_gather_and_pooling_epilogue(gpu_device, g):
+    """The image is NOT zero-padded: per-pixel tap masks make the loaders read border taps as zero.  Forward, weight
+    gradient and data gradient must equal the padded-copy path bit for bit (same products, same order); with
+    pool-ordered tables the forward GEMM's epilogue must produce exactly what conv -> ReLU -> 2x2 max pooling does,
+    arg-max included, and the pooled-mask pooling gradient what the full-resolution mask gives."""
+    gen = torch.Generator().manual_seed(9)
+    B, H, W, C, N, KH, KW = (g[k] for k in ("B", "H", "W", "C", "N", "KH", "KW"))
+    x = torch.randn(B, H, W, C, generator=gen).to(gpu_device)
+    w = (torch.randn(KH, KW, C, N, generator=gen) * 0.1).to(gpu_device)
+    b = torch.randn(N, generator=gen).to(gpu_device)
+    OH, OW, pt, pl, pb, pr = F.conv_geometry(H, W, KH, KW, (1, 1), g["padding"])
+    M, K = B * OH * OW, KH * KW * C
+    Hp, Wp = H + pt + pb, W + pl + pr
+    xpad = F.conv_pad(x, pt, pl, Hp, Wp)
+    rt_p, sh_p = F.conv_tables(B, OH, OW, Hp, Wp, KH, KW, C, gpu_device)
+    rt, sh, mk = F.conv_tables_unpadded(B, OH, OW, H, W, KH, KW, pt, pl, C, gpu_device)
+    y_ref = F.conv_gemm_forward(xpad, rt_p, sh_p, w.view(K, N), b, F.ACT_RELU, torch.empty(M, N, device=gpu_device))
+    y = F.conv_gemm_forward(x, rt, sh, w.view(K, N), b, F.ACT_RELU, torch.empty(M, N, device=gpu_device), masktab=mk)
+    assert torch.equal(y, y_ref)
+    dz = torch.randn(M, N, generator=gen).to(gpu_device)
+    ws = torch.empty(max(F.dense_dw_workspace_floats(M, N, K), 1), device=gpu_device)
+    dw_ref, db_ref = torch.empty(K, N, device=gpu_device), torch.empty(N, device=gpu_device)
+    F.conv_gemm_wgrad(xpad, rt_p, sh_p, dz, dw_ref, db_ref, ws)
+    dw, db = torch.full((K, N), float("nan"), device=gpu_device), torch.full((N,), float("nan"), device=gpu_device)
+    F.conv_gemm_wgrad(x, rt, sh, dz, dw, db, ws, masktab=mk)
+    assert torch.equal(dw, dw_ref) and torch.equal(db, db_ref)
+    top, left = KH - 1 - pt, KW - 1 - pl
+    dzpad = F.conv_pad(dz.view(B, OH, OW, N), top, left, H + KH - 1, W + KW - 1)
+    rtd_p, shd_p = F.conv_tables(B, H, W, H + KH - 1, W + KW - 1, KH, KW, N, gpu_device)
+    rtd, shd, mkd = F.conv_tables_unpadded(B, H, W, OH, OW, KH, KW, top, left, N, gpu_device)
+    wflip = F.conv_flip_weights(w)
+    dx_ref = F.conv_gemm_dgrad(dzpad, rtd_p, shd_p, wflip, torch.empty(B * H * W, C, device=gpu_device))
+    dx = F.conv_gemm_dgrad(dz.view(B, OH, OW, N), rtd, shd, wflip, torch.empty(B * H * W, C, device=gpu_device), masktab=mkd)
+    assert torch.equal(dx, dx_ref)
+    if OH % 2 == 0 and OW % 2 == 0:
+        rt2, sh2, mk2 = F.conv_tables_unpadded(B, OH, OW, H, W, KH, KW, pt, pl, C, gpu_device, pool_order=True)
+        yp = torch.full((B * (OH // 2) * (OW // 2), N), float("nan"), device=gpu_device)
+        arg = torch.full((B, OH // 2, OW // 2, N), 255, dtype=torch.uint8, device=gpu_device)
+        F.conv_gemm_forward(x, rt2, sh2, w.view(K, N), b, F.ACT_RELU, yp, masktab=mk2, pool_arg=arg)
+        yp_ref, arg_ref = F.maxpool_forward(y_ref.view(B, OH, OW, N), (2, 2))
+        assert torch.equal(yp.view(yp_ref.shape), yp_ref) and torch.equal(arg, arg_ref)
+        dyp = torch.randn(yp_ref.shape, generator=gen).to(gpu_device)
+        full = F.maxpool_backward(dyp, arg_ref, (B, OH, OW, N), (2, 2), x_relu=y_ref.view(B, OH, OW, N))
+        pooled = F.maxpool_backward(dyp, arg, (B, OH, OW, N), (2, 2), x_relu=yp.view(yp_ref.shape), mask_pooled=True)
+        assert torch.equal(pooled, full)
+        # CPU reference of the pooled-mask variant
+        cpu = F.maxpool_backward(dyp.cpu(), arg.cpu(), (B, OH, OW, N), (2, 2), x_relu=yp.view(yp_ref.shape).cpu(), mask_pooled=True)
+        assert torch.equal(cpu, full.cpu())
