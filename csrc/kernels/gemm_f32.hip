@@ -72,6 +72,8 @@ struct GemmArgs {
     // wgrad extras
     float* colsum;            // partial bias gradients of split 0 (may be null)
     long long colsum_split_stride;  // elements between successive splits' colsum rows
+    int single_lds;           // one LDS stage instead of two (tuning aid DTF_GEMM_SINGLE): half the LDS per block, so twice
+                              // the resident blocks, for a second barrier per k tile
     int dbg;                  // DTF_GEMM_DBG bit 8: every block stamps its main-loop time over its first outputs; 0 in production
     // implicit-GEMM convolution (GATHER kernels): operand A is the patch matrix of a zero-padded NHWC image that is
     // never materialised.  Patch row m starts at element g_rowtab[m] of the image; window position w = k / g_C
@@ -616,6 +618,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
     // latency once per k-group.  In the last k-group of a tile the same slot holds the store of the next tile, the
     // barrier and the request for that tile's first fragments, so these are covered by 3*TM*TN MFMAs as well.
     int stage = 0;
+    const int stage_stride = p.single_lds ? 0 : STAGE;
     f32x4 fa[2][TM], fb[2][TN];
     {
         const float* As = smem;
@@ -633,7 +636,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
     constexpr bool LIVE = decltype(live_tag)::value;
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         const bool more = (k0 + BK) < kend;
-        const float* As = smem + stage * STAGE;
+        const float* As = smem + stage * stage_stride;
         const float* Bs = As + LoadA::LDS_FLOATS;
         if (more && !(p.dbg & 1)) {     // bit 1 (diagnostic): no global loads after the first tile
             la.load(k0 + BK, kbeg, kend - k0 - BK, tid);
@@ -668,7 +671,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
                 }
                 // Unconditional barrier and reads (after the last tile they fetch stale data nobody uses): one path
                 // through here lets the compiler count outstanding LDS operations exactly instead of draining them.
-                float* nx = smem + (stage ^ 1) * STAGE;
+                float* nx = smem + (stage ^ 1) * stage_stride;
+                if (p.single_lds) __syncthreads();      // every wave has its fragments of this tile in registers
                 if (more) {
                     la.store(nx, kend - k0 - BK, tid);
                     lb.store(nx + LoadA::LDS_FLOATS, kend - k0 - BK, tid);
@@ -970,7 +974,13 @@ template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int EPI, bool GA
 int launch_cfg(const GemmArgs& a, int splits, hipStream_t s) {
     using LoadA = TileLoader<BM, A_KC>;     // the gather loaders build the same LDS images
     using LoadB = TileLoader<BN, B_KC>;
-    const size_t lds = 2 * (LoadA::LDS_FLOATS + LoadB::LDS_FLOATS) * sizeof(float);
+    // One LDS stage for the implicit-GEMM convolutions: their small tiles (N = 32 / 64 output channels) leave two
+    // resident blocks per CU with two stages, and the gather loaders' longer address arithmetic wants more waves to
+    // hide behind (measured on the MNIST CNN: 3.07 -> 3.00 ms/step; the dense layers of the MLP did not move).
+    // DTF_GEMM_SINGLE=0/1 overrides for every kernel.
+    static const int forced = getenv("DTF_GEMM_SINGLE") ? atoi(getenv("DTF_GEMM_SINGLE")) : -1;
+    const int single = forced >= 0 ? forced : (GATHER ? 1 : 0);
+    const size_t lds = (single ? 1 : 2) * (LoadA::LDS_FLOATS + LoadB::LDS_FLOATS) * sizeof(float);
     auto kern = gemm_f32_kernel<BM, BN, WM, WN, A_KC, B_KC, EPI, GATHER>;
     if (lds > 48 * 1024) {
         static bool once = false;  // per instantiation
@@ -984,6 +994,7 @@ int launch_cfg(const GemmArgs& a, int splits, hipStream_t s) {
     dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, splits);
     GemmArgs args = a;
     args.dbg = env_dbg();
+    args.single_lds = single;
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, args);
     DTF_CHECK_LAUNCH();
     return 0;
