@@ -657,10 +657,17 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
             }
             __builtin_amdgcn_sched_barrier(0);
             if (kk < LAST) {
+                if (!(p.dbg & 16)) {      // bit 16 (diagnostic): no fragment reads inside a tile
 #pragma unroll
-                for (int i = 0; i < TM; ++i) fa[nxt][i] = read_frag<BM, A_KC>(As, (wm * TM + i) * 32 + li, kk + 1, h);
+                    for (int i = 0; i < TM; ++i) fa[nxt][i] = read_frag<BM, A_KC>(As, (wm * TM + i) * 32 + li, kk + 1, h);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) fb[nxt][j] = read_frag<BN, B_KC>(Bs, (wn * TN + j) * 32 + li, kk + 1, h);
+                    for (int j = 0; j < TN; ++j) fb[nxt][j] = read_frag<BN, B_KC>(Bs, (wn * TN + j) * 32 + li, kk + 1, h);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) fa[nxt][i] = fa[cur][i];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) fb[nxt][j] = fb[cur][j];
+                }
             } else {
                 if (EPI == EPI_DW) {
                     if (do_colsum && tid < BN) {
@@ -673,11 +680,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
                 // through here lets the compiler count outstanding LDS operations exactly instead of draining them.
                 float* nx = smem + (stage ^ 1) * stage_stride;
                 if (p.single_lds) __syncthreads();      // every wave has its fragments of this tile in registers
-                if (more) {
+                if (more && !(p.dbg & 4)) {     // bit 4 (diagnostic): no LDS stores after the first tile
                     la.store(nx, kend - k0 - BK, tid);
                     lb.store(nx + LoadA::LDS_FLOATS, kend - k0 - BK, tid);
                 }
-                __syncthreads();
+                if (!(p.dbg & 2)) __syncthreads();      // bit 2 (diagnostic): no barrier inside the loop
                 const float* An = nx;
                 const float* Bn = nx + LoadA::LDS_FLOATS;
 #pragma unroll
