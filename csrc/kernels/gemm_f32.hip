@@ -85,7 +85,7 @@ struct GemmArgs {
                               // origin of the window - may be negative for rows at the image border.
     const int* g_shift;       // [KH*KW]
     int g_rows;
-    int g_C;                  // channels per window position (multiple of 32 for k-contiguous A, of 4 otherwise)
+    int g_C;                  // channels per window position (multiple of 4; multiples of 32 take the uniform fast path)
     long long g_elems;        // elements of the padded image
 };
 
@@ -364,13 +364,23 @@ struct GatherLoader<ROWS, true> {
         }
     }
     __device__ __forceinline__ void load(int k0, int kbeg, int k_left, int tid) {
-        const int w = k0 / C;                           // uniform: a 32-deep k tile lies inside one window position
-        const int sh = shift[w] + (k0 % C);
+        // All vectors of a thread sit in the same k column c = (tid & 7) * 4 of the tile.  With C a multiple of the tile
+        // depth the whole tile lies inside one window position (w and the shift are uniform); otherwise C is a multiple
+        // of 4, a vector still lies inside one position, and every thread finds its own (one division per thread and tile).
+        const int c = (tid & 7) * 4;
+        int w, sh;
+        if (C % BK == 0) {
+            w = k0 / C;
+            sh = shift[w] + (k0 % C) + c;
+        } else {
+            const int k = min(k0 + c, k0 + k_left - 1);      // past the end of K: any valid position, the load is masked
+            w = k / C;
+            sh = shift[w] + (k - w * C);
+        }
 #pragma unroll
         for (int s = 0; s < NV; ++s) {
-            const int c = ((tid + 256 * s) & 7) * 4;
             const bool ok = ((taps[s] >> w) & 1u) && (c < k_left);
-            const unsigned off = (unsigned)(rb[s] + sh + c) * 4u;
+            const unsigned off = (unsigned)(rb[s] + sh) * 4u;
             const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(ok ? off : OOB), 0, 0);
             v[s] = __builtin_bit_cast(f32x4, raw);
         }
@@ -379,7 +389,7 @@ struct GatherLoader<ROWS, true> {
 #pragma unroll
         for (int s = 0; s < NV; ++s) {
             const int id = tid + 256 * s;
-            *reinterpret_cast<f32x4*>(lds + (id >> 3) * LDK + (id & 7) * 4) = v[s];    // K is a multiple of BK: no tail
+            *reinterpret_cast<f32x4*>(lds + (id >> 3) * LDK + (id & 7) * 4) = v[s];    // K is a multiple of 4: vectors past it were loaded as zeros
         }
     }
 };
@@ -1323,7 +1333,7 @@ DTF_API int dtf_dense_bwd_dw(const float* X, const float* dZ, float* dW, float* 
 // patch row m lives at rowtab[m] in the padded image, window position w at + shift[w], channels contiguous.
 
 static bool gather_ok(const int* rowtab, const int* shift, int C, int K, bool a_kc) {
-    return rowtab && shift && C > 0 && K % C == 0 && (a_kc ? C % BK == 0 : C % 4 == 0);
+    return rowtab && shift && C > 0 && K % C == 0 && C % 4 == 0;
 }
 
 // Y[M,N] = act(patches(Xpad)[M,K] . W[K,N] + b), K = KH*KW*C

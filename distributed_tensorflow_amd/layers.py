@@ -294,7 +294,7 @@ class Conv2D(Layer):
     Executed as patch matrix x filter matrix on the MFMA GEMM kernels: the kernel variable viewed as
     ``[kh*kw*cin, cout]`` is the GEMM's B operand as stored, the GEMM output ``[B*OH*OW, cout]`` is the NHWC result as
     stored, and bias / activation / bias-gradient ride in the GEMM epilogues exactly as for ``Dense``.  On the GPU
-    with stride 1 and channel counts that are multiples of 32 the patch matrix is implicit: the GEMM's operand loader
+    with stride 1 and channel counts that are multiples of 4 the patch matrix is implicit: the GEMM's operand loader
     gathers patch rows from a zero-padded copy of the image (forward and weight gradient), and the data gradient is
     the same kind of convolution over the zero-padded output gradient with the flipped filter.  Other shapes
     materialise the patch matrix, keep it from forward to backward (wgrad reads it) and reuse it as the buffer of
@@ -363,7 +363,7 @@ class Conv2D(Layer):
         cols = self._buf.get("cols", (B * OH * OW, kh * kw * C), x.device)
         return F.im2col(x, kh, kw, self.strides, self.padding, out=cols)
 
-    # ---- implicit-GEMM path (GPU, stride 1, 32-channel multiples): the GEMM kernels gather patch rows straight from
+    # ---- implicit-GEMM path (GPU, stride 1, 4-channel multiples): the GEMM kernels gather patch rows straight from
     #      a zero-padded copy of the image, so no [B*OH*OW, kh*kw*cin] matrix ever exists in HBM
     def _implicit(self, x) -> bool:
         if not x.is_cuda or self.kernel_size == (1, 1):

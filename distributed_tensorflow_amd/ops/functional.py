@@ -669,10 +669,11 @@ def mlp_tail(h1, w2, b2, w3, b3, labels, dz1, dw2, db2, dw3, db3, workspace, kee
 
 # ----------------------------------------------------------------------------- implicit-GEMM convolution (GPU, stride 1)
 def conv_implicit_supported(c_in: int, c_out: int, strides, need_dgrad: bool = True) -> bool:
-    """The GEMM kernels can gather patch rows straight from a zero-padded image (no patch matrix in HBM) when the
-    stride is 1 and a 32-deep k tile lies inside one window position: ``c_in % 32 == 0`` (and ``c_out % 32 == 0``
-    for the data gradient, which is a convolution over the output gradient)."""
-    return tuple(strides) == (1, 1) and c_in % 32 == 0 and (not need_dgrad or c_out % 32 == 0) and nv.kernels_available() \
+    """The GEMM kernels can gather patch rows straight from the image (no patch matrix in HBM) when the stride is 1
+    and a 4-float vector lies inside one window position: ``c_in % 4 == 0`` (and ``c_out % 4 == 0`` for the data
+    gradient, which is a convolution over the output gradient).  Multiples of 32 channels take the loaders' fast path
+    (a whole 32-deep k tile inside one window position)."""
+    return tuple(strides) == (1, 1) and c_in % 4 == 0 and (not need_dgrad or c_out % 4 == 0) and nv.kernels_available() \
         and hasattr(nv.kernels(), "dtf_conv_gemm_fwd")
 
 

@@ -93,6 +93,11 @@ def test_mnist_cnn_learns(gpu_device):
     dict(B=3, H=9, W=11, C=64, N=32, KH=3, KW=3, padding="valid"),
     dict(B=2, H=8, W=8, C=32, N=96, KH=2, KW=3, padding="same"),
     dict(B=70, H=14, W=14, C=32, N=64, KH=5, KW=5, padding="same"),
+    # channel counts that are multiples of 4 only: a k tile spans several window positions, K has a tail
+    dict(B=5, H=9, W=10, C=4, N=8, KH=3, KW=3, padding="same"),
+    dict(B=3, H=12, W=12, C=12, N=20, KH=5, KW=5, padding="valid"),
+    dict(B=4, H=7, W=9, C=40, N=24, KH=2, KW=3, padding="same"),
+    dict(B=9, H=6, W=6, C=8, N=4, KH=3, KW=1, padding="same"),
 ])
 def test_implicit_gemm_conv_matches_patch_matrix_path(gpu_device, g):
     """Forward, weight gradient and data gradient with the patches gathered inside the GEMM against the same
@@ -134,25 +139,26 @@ def test_implicit_gemm_conv_matches_patch_matrix_path(gpu_device, g):
     torch.testing.assert_close(dx.view(B, H, W, C), dx_ref, rtol=1e-3, atol=1e-3)
 
 
-def test_cnn_with_implicit_convs_matches_autograd(gpu_device):
-    """A model whose convolutions take the implicit-GEMM path (32-channel multiples, stride 1): every gradient against
+@pytest.mark.parametrize("c0,c1,c2", [(32, 32, 64), (4, 12, 20)])
+def test_cnn_with_implicit_convs_matches_autograd(gpu_device, c0, c1, c2):
+    """A model whose convolutions take the implicit-GEMM path (4-channel multiples, stride 1): every gradient against
     PyTorch autograd on the CPU."""
     from distributed_tensorflow_amd.layers import Conv2D, Dense, Flatten, MaxPooling2D
     from distributed_tensorflow_amd.models import Sequential
 
     def build():
         return Sequential([
-            Conv2D(32, (3, 3), padding="same", activation="relu", input_shape=(8, 8, 32)),
-            Conv2D(64, (3, 3), padding="valid", activation="relu"),
+            Conv2D(c1, (3, 3), padding="same", activation="relu", input_shape=(8, 8, c0)),
+            Conv2D(c2, (3, 3), padding="valid", activation="relu"),
             MaxPooling2D((2, 2)),
-            Conv2D(32, (2, 2), padding="same", activation="relu"),
+            Conv2D(c1, (2, 2), padding="same", activation="relu"),
             Flatten(),
             Dense(5, activation="softmax"),
         ])
     m = build()
     m.compile(loss="sparse_categorical_crossentropy", optimizer="sgd", metrics=["accuracy"], device=gpu_device, seed=3)
     gen = torch.Generator().manual_seed(5)
-    x = torch.randn(6, 8, 8, 32, generator=gen)
+    x = torch.randn(6, 8, 8, c0, generator=gen)
     y = torch.randint(0, 5, (6,), generator=gen)
     m.compute_gradients(x.to(gpu_device), y.to(gpu_device))
     convs = [l for l in m.layers if isinstance(l, Conv2D)]
@@ -170,6 +176,8 @@ def test_cnn_with_implicit_convs_matches_autograd(gpu_device):
     dict(B=4, H=14, W=14, C=32, N=64, KH=5, KW=5, padding="same"),
     dict(B=3, H=10, W=12, C=64, N=32, KH=3, KW=3, padding="valid"),
     dict(B=2, H=8, W=8, C=32, N=96, KH=2, KW=3, padding="same"),
+    dict(B=3, H=8, W=10, C=12, N=20, KH=3, KW=3, padding="same"),
+    dict(B=2, H=6, W=6, C=4, N=8, KH=5, KW=5, padding="same"),
 ])
 def test_unpadded_gather_and_pooling_epilogue(gpu_device, g):
     """The image is NOT zero-padded: per-pixel tap masks make the loaders read border taps as zero.  Forward, weight

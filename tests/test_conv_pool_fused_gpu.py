@@ -59,7 +59,7 @@ def test_fused_conv_pool_matches_pytorch(gpu_device, B, H, W, C, KH, KW, Fo, pad
 
 def test_shapes_outside_the_fused_kernels_are_reported(gpu_device):
     assert not F.conv_pool_supported((4, 28, 28, 32), 5, 5, 64)           # 800 taps: the implicit-GEMM path's job
-    assert not F.conv_pool_supported((4, 28, 28, 1), 5, 5, 10)            # channel count not a multiple of 32
+    assert not F.conv_pool_supported((4, 28, 28, 1), 5, 5, 10)            # 10 filters: not a multiple of 32
     assert not F.conv_pool_supported((4, 27, 27, 1), 5, 5, 32, padding="same")    # odd conv output: windows do not tile it
     assert not F.conv_pool_supported((4, 28, 28, 1), 5, 5, 32, strides=(2, 2))
 
