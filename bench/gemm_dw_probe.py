@@ -1,5 +1,6 @@
 """Per-block timing of the split-batch wgrad GEMM (DTF_GEMM_DBG=8: every block writes loop cycles, ticks, loop-only
-cycles, entry and exit stamps over the first five outputs of its tile in its slab)."""
+cycles, entry and exit stamps, HW_ID and XCC_ID over the first seven outputs of its tile in its slab).  WARM=n runs n
+launches first so the clock is the steady one."""
 import os
 import sys
 
@@ -18,7 +19,7 @@ dw = torch.empty(K, N, device=dev)
 db = torch.empty(N, device=dev)
 splits = nv.kernels().dtf_dense_bwd_dw_splits(M, N, K)
 ws = torch.zeros(max(F.dense_dw_workspace_floats(M, N, K), 1), device=dev)
-for _ in range(3):
+for _ in range(int(os.environ.get("WARM", 3))):
     F.dense_backward_dw(x, dz, dw, db, workspace=ws)
 torch.cuda.synchronize()
 a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -35,7 +36,7 @@ w = ws.cpu().double()
 for s in range(eff):
     for ty in range(tiles):
         o = s * stride + ty * BM * N
-        rows.append(w[o:o + 5])
+        rows.append(w[o:o + 7])
 t = torch.stack(rows)
 cyc, us, loop = t[:, 0], t[:, 1] / 100.0, t[:, 2]
 entry, exit_ = t[:, 3], t[:, 4]
@@ -55,3 +56,24 @@ zs = ids // tiles
 print("by split (every 6th): " + " ".join("%.0f" % us[zs == k].mean() for k in range(0, eff, 6)))
 print("hist us: ", torch.histc(us.float(), bins=10, min=float(us.min()), max=float(us.max()) + 1e-3).tolist())
 print("loop-only us hist: ", torch.histc((loop / 2062).float(), bins=10).tolist(), float((loop / 2062).min()), float((loop / 2062).max()))
+# placement: which CU ran which blocks, when they started, how much loop work each CU got
+hw, xcc = t[:, 5].long(), t[:, 6].long()
+cu = (xcc << 16) | (hw & 0xFF00)
+per = {}
+for i in range(len(rows)):
+    per.setdefault(int(cu[i]), []).append(i)
+sizes = {}
+for v in per.values():
+    sizes[len(v)] = sizes.get(len(v), 0) + 1
+print("distinct CUs %d; blocks per CU histogram %s" % (len(per), dict(sorted(sizes.items()))))
+late = (entry - e0) / 100 > 20
+print("blocks entering later than 20 us after the first: %d (entry us: %s)" % (int(late.sum()), sorted(((entry - e0) / 100)[late].tolist())[:12]))
+work = torch.tensor([sum(float(loop[i]) for i in v) for v in per.values()])
+last = torch.tensor([max(float(exit_[i] - e0) / 100 for i in v) for v in per.values()])
+print("per-CU sum of loop cycles: mean %.0f min %.0f max %.0f; per-CU last exit us: mean %.1f min %.1f max %.1f" % (
+    work.mean(), work.min(), work.max(), last.mean(), last.min(), last.max()))
+for n_on_cu in sorted(sizes):
+    sel = [k for k, v in per.items() if len(v) == n_on_cu]
+    print("  CUs with %d blocks: last exit mean %.1f us; block us mean %.1f" % (
+        n_on_cu, sum(max(float(exit_[i] - e0) / 100 for i in per[k]) for k in sel) / len(sel),
+        sum(float(us[i]) for k in sel for i in per[k]) / sum(len(per[k]) for k in sel)))

@@ -72,6 +72,10 @@ struct GemmArgs {
     // wgrad extras
     float* colsum;            // partial bias gradients of split 0 (may be null)
     long long colsum_split_stride;  // elements between successive splits' colsum rows
+    int colsum_mfma;          // the column sums ride on the matrix cores: the loader sets the first padding row of A (row M,
+                              // inside the last, partly filled 32-row sub-tile) to ones, so row M of the product IS
+                              // colsum(B) and the epilogue routes it to `colsum`.  Needs M % 32 != 0.  Otherwise the block
+                              // of row tile 0 sums the B tile's columns from LDS (15 % longer than its neighbours).
     int single_lds;           // one LDS stage instead of two (tuning aid DTF_GEMM_SINGLE): half the LDS per block, so twice
                               // the resident blocks, for a second barrier per k tile
     int dbg;                  // DTF_GEMM_DBG bit 8: every block stamps its main-loop time over its first outputs; 0 in production
@@ -121,6 +125,7 @@ struct TileLoader {
     int mn_left;   // valid rows/cols of the M/N dimension from this block's origin
     unsigned voff[NV];   // byte offset of this thread's vectors inside the first k tile; OOB if its row/column is outside
     f32x4 v[NV];
+    bool ones_row = false;   // M/N-contiguous images only: the first index past the operand (mn_left) is stored as 1.0
 
     // base points at element (mn0, kbeg) of the operand; rows_total/k_total bound the allocation
     __device__ __forceinline__ void init(const float* base, int ld_, int mn0, int mn_dim, int kbeg, int k_total) {
@@ -204,6 +209,10 @@ struct TileLoader {
             f32x4 x = v[s];
 #pragma unroll
             for (int j = 1; j < 4; ++j) x[j] = (j < lim) ? x[j] : 0.f;
+            if (!KC && ones_row) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) x[j] = (j == lim) ? 1.0f : x[j];
+            }
             *reinterpret_cast<f32x4*>(lds + off) = x;
         }
     }
@@ -533,6 +542,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int dr = (r & 3) + 8 * (r >> 2);
+                    if (CHECK && EPI == EPI_DW && p.colsum_mfma && row0 + dr == p.M && p.colsum) {
+                        p.colsum[(long long)blockIdx.z * p.colsum_split_stride + col] = acc[i][j][r];    // ones row . B
+                        continue;
+                    }
                     if (CHECK && row0 + dr >= p.M) continue;
                     float v = acc[i][j][r];
                     if (EPI == EPI_FWD) {
@@ -607,12 +620,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
     // does this wave own any output inside C?  (TM x TN sub-tiles starting at its first row / column)
     const bool wave_live = (m0 + wm * TM * 32 < p.M) && (n0 + wn * TN * 32 < p.N);
     float csum = 0.f;  // wgrad: partial bias gradient of column n0 + tid
-    const bool do_colsum = (EPI == EPI_DW) && (p.colsum != nullptr) && (blockIdx.y == 0);
+    const bool do_colsum = (EPI == EPI_DW) && (p.colsum != nullptr) && (blockIdx.y == 0) && !p.colsum_mfma;
 
     LoadA la;
     LoadB lb;
     if constexpr (GATHER) la.init_gather(p, m0, kbeg, tid);
-    else la.init(p.A, p.lda, m0, p.M, kbeg, p.K);
+    else {
+        la.init(p.A, p.lda, m0, p.M, kbeg, p.K);
+        if constexpr (EPI == EPI_DW && !A_KC) la.ones_row = p.colsum_mfma && p.colsum != nullptr;
+    }
     lb.init(p.B, p.ldb, n0, p.N, kbeg, p.K);
     la.load(kbeg, kbeg, kend - kbeg, tid);
     lb.load(kbeg, kbeg, kend - kbeg, tid);
@@ -730,6 +746,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
         C[(long long)m0 * p.ldc + n0 + 2] = (float)(dbg_t1 - dbg_t0);
         C[(long long)m0 * p.ldc + n0 + 3] = (float)(dbg_entry & 0xFFFFF);                         // block entry, 10 ns ticks
         C[(long long)m0 * p.ldc + n0 + 4] = (float)(__builtin_amdgcn_s_memrealtime() & 0xFFFFF);  // block exit
+        // where wave 0 ran: HW_ID (wave slot [3:0], SIMD [5:4], CU [11:8], SH [12], SE [15:13]) and XCC_ID
+        C[(long long)m0 * p.ldc + n0 + 5] = (float)(__builtin_amdgcn_s_getreg(4 | (31 << 11)) & 0xFFFF);
+        C[(long long)m0 * p.ldc + n0 + 6] = (float)(__builtin_amdgcn_s_getreg(20 | (31 << 11)) & 0xF);
     }
     if (EPI == EPI_DW) {
         if (do_colsum && tid < BN && (n0 + tid) < p.N)
@@ -1308,6 +1327,8 @@ DTF_API int dtf_dense_bwd_dw(const float* X, const float* dZ, float* dW, float* 
     chunk = ((chunk + BK - 1) / BK) * BK;
     a.k_chunk = chunk;
     const int eff_splits = (M + chunk - 1) / chunk;
+    static const int colsum_on_mfma = getenv("DTF_COLSUM_MFMA") ? atoi(getenv("DTF_COLSUM_MFMA")) : 1;
+    a.colsum_mfma = (colsum_on_mfma && db && K % 32 != 0 && !split_products()) ? 1 : 0;
     if (eff_splits <= 1) {
         a.C = dW; a.c_split_stride = 0; a.colsum = db;
         return launch_gemm<false, false, EPI_DW>(a, 1, stream, hint);
