@@ -37,7 +37,8 @@ def _worker(rank, world, port, bucket_bytes, allreduce_below, out_q):
     for _ in range(5):
         m.train_step(xs, ys)
     logs = m.read_stats()
-    out_q.put((rank, m.store.flat.clone(), m.global_step, logs, len(strat.buckets), strat.replicated))
+    # by value (numpy), not as a shared-memory tensor: the parent may unpickle it after this process has exited
+    out_q.put((rank, m.store.flat.clone().numpy(), m.global_step, logs, len(strat.buckets), strat.replicated))
     import torch.distributed as dist
     dist.barrier()
     dist.destroy_process_group()
@@ -54,6 +55,7 @@ def test_sync_replicas_matches_single_process(bucket_bytes, allreduce_below, wor
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    res = [(r[0], torch.from_numpy(r[1])) + tuple(r[2:]) for r in res]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
