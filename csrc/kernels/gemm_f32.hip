@@ -584,8 +584,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
     }
 }
 
+// A wave that owns a single 32x32 sub-tile needs few registers; asking for six waves per SIMD keeps the compiler under
+// 80 (it took 82-88 on its own, which is five waves): the small-tile kernels - thin outputs, convolution gathers - hide
+// their load latency behind resident waves, not behind long MFMA runs.
 template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int EPI, bool GATHER = false>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(256, (BM / WM == 32 && BN / WN == 32) ? 8 : 1) void gemm_f32_kernel(const GemmArgs p) {
     static_assert(WM * WN == 4, "block is four waves");
     constexpr int TM = BM / WM / 32;
     constexpr int TN = BN / WN / 32;
@@ -1052,10 +1055,11 @@ inline size_t tile_lds_bytes(int bm, int bn, bool a_kc, bool b_kc) {
 
 constexpr double BLOCK_OVERHEAD_CYCLES = 6000.0;   // first-tile latency + epilogue of one block (measured ~3 us)
 
-inline double tile_cost(long long M, long long N, long long kc, int splits, int bm, int bn, bool a_kc, bool b_kc) {
+inline double tile_cost(long long M, long long N, long long kc, int splits, int bm, int bn, bool a_kc, bool b_kc,
+                        long long res_known = 0) {
     const long long nb = ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * splits;
-    long long res = (long long)((160 * 1024) / tile_lds_bytes(bm, bn, a_kc, b_kc));
-    if (res > 4) res = 4;
+    long long res = res_known > 0 ? res_known : (long long)((160 * 1024) / tile_lds_bytes(bm, bn, a_kc, b_kc));
+    if (res_known <= 0 && res > 4) res = 4;
     const long long slots = 256 * res;
     const long long full = nb / slots, rem = nb % slots;
     const long long seq = full * res + (rem + 255) / 256;          // blocks the busiest CU runs one after another
@@ -1092,11 +1096,15 @@ int launch_tiled(const GemmArgs& a, int splits, hipStream_t s, int tile_hint) {
     if constexpr (!GATHER) {
         if (split_products() && split_shape_ok(a, splits)) return launch_x3<A_KC, B_KC, EPI>(a, splits, split_products(), s);
     }
+    // Tile codes: 128 (=128x128), 6428 (=64x128), 64 (=64x64), 12864 (=128x64: two 32x32 sub-tiles per wave on a
+    // 64-column output, three fragment reads per eight MFMAs where the 64x64 tile needs two per four).
+    int t = env_tile() ? env_tile() : tile_hint;
     if (a.N <= 32) return launch_cfg<128, 32, 4, 1, A_KC, B_KC, EPI, GATHER>(a, splits, s);
-    int t = tile_hint;
-    if (a.N <= 64 || a.M <= 64) t = 64;
-    else if (env_tile()) t = env_tile();
-    else if (t != 64 && t != 128 && t != 6428) t = pick_tile(a, splits, A_KC, B_KC);
+    if (a.N <= 64 || a.M <= 64) {
+        if (t == 12864 && a.M >= 128) return launch_cfg<128, 64, 2, 2, A_KC, B_KC, EPI, GATHER>(a, splits, s);
+        return launch_cfg<64, 64, 2, 2, A_KC, B_KC, EPI, GATHER>(a, splits, s);
+    }
+    if (t != 64 && t != 128 && t != 6428) t = pick_tile(a, splits, A_KC, B_KC);
     if (t == 128) return launch_cfg<128, 128, 2, 2, A_KC, B_KC, EPI, GATHER>(a, splits, s);
     if (t == 6428) return launch_cfg<64, 128, 2, 2, A_KC, B_KC, EPI, GATHER>(a, splits, s);
     return launch_cfg<64, 64, 2, 2, A_KC, B_KC, EPI, GATHER>(a, splits, s);
@@ -1266,7 +1274,49 @@ DTF_API int dtf_dense_bwd_dx(const float* dZ, const float* W, float* dX, int M, 
 // reduction (each split writes, and the reducer reads, a K x N slab).
 struct DwPlan { int tile; int splits; };
 
-static DwPlan dw_plan(int M, int N, int K) {
+inline int gemm_single_stage(bool gather) {     // the rule of launch_cfg
+    static const int forced = getenv("DTF_GEMM_SINGLE") ? atoi(getenv("DTF_GEMM_SINGLE")) : -1;
+    return forced >= 0 ? forced : (gather ? 1 : 0);
+}
+
+// Workgroups of a wgrad kernel instantiation one CU holds at once, as the runtime computes it from the kernel's
+// registers and LDS (the 64x64 gather kernel: 82 registers -> 5 waves per SIMD, although its 17 KB of LDS would
+// allow nine).  The split count is chosen to fill exactly these slots: one block more and a second round starts
+// (measured on the MNIST CNN's second convolution: 98 splits 807 us, 99 splits 945 us).
+template <int BM, int BN, int WM, int WN, bool GATHER>
+static int wgrad_resident_blocks() {
+    static int cached = 0;
+    if (cached) return cached;
+    using LoadA = TileLoader<BM, false>;
+    using LoadB = TileLoader<BN, false>;
+    const size_t lds = (gemm_single_stage(GATHER) ? 1 : 2) * (LoadA::LDS_FLOATS + LoadB::LDS_FLOATS) * sizeof(float);
+    auto kern = gemm_f32_kernel<BM, BN, WM, WN, false, false, EPI_DW, GATHER>;
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, 256, lds) != hipSuccess || n < 1) {
+        (void)hipGetLastError();
+        n = (int)((160 * 1024) / lds);
+        if (n > 4) n = 4;
+    }
+    cached = n > 8 ? 8 : n;
+    return cached;
+}
+
+static int wgrad_resident(int tile, bool gather) {
+    if (gather) {
+        if (tile == 128) return wgrad_resident_blocks<128, 128, 2, 2, true>();
+        if (tile == 6428) return wgrad_resident_blocks<64, 128, 2, 2, true>();
+        if (tile == 32) return wgrad_resident_blocks<128, 32, 4, 1, true>();
+        return wgrad_resident_blocks<64, 64, 2, 2, true>();
+    }
+    if (tile == 128) return wgrad_resident_blocks<128, 128, 2, 2, false>();
+    if (tile == 6428) return wgrad_resident_blocks<64, 128, 2, 2, false>();
+    if (tile == 32) return wgrad_resident_blocks<128, 32, 4, 1, false>();
+    return wgrad_resident_blocks<64, 64, 2, 2, false>();
+}
+
+static DwPlan dw_plan(int M, int N, int K, bool gather = false) {
     if (const char* e = getenv("DTF_DW_PLAN")) {     // tuning aid: "tile,splits"
         int t = 0, sp = 0;
         if (sscanf(e, "%d,%d", &t, &sp) == 2 && sp >= 1) return {t, sp};
@@ -1292,25 +1342,26 @@ static DwPlan dw_plan(int M, int N, int K) {
         const int bm = cand[c][0], bn = cand[c][1];
         if ((K <= 64 || N <= 64) && cand[c][2] != 64) continue;
         const long long tiles = (long long)((K + bm - 1) / bm) * ((N + bn - 1) / bn);
-        long long res = (long long)((160 * 1024) / tile_lds_bytes(bm, bn, false, false));
-        if (res > 4) res = 4;
+        const long long res = wgrad_resident(cand[c][2], gather);
         long long want = (256 * res) / tiles;
         if (want < 1) want = 1;
         int sp = (int)(want < max_by_m ? want : max_by_m);
         int chunk = (((M + sp - 1) / sp + BK - 1) / BK) * BK;
         sp = (M + chunk - 1) / chunk;
-        double cost = tile_cost(K, N, chunk, sp, bm, bn, false, false);
+        double cost = tile_cost(K, N, chunk, sp, bm, bn, false, false, res);
         if (sp > 1) cost += 2.0 * sp * (double)K * N * 4.0 * 0.0007;     // slab bytes at ~3 TB/s, in 2.1 GHz cycles
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = {cand[c][2], sp}; }
     }
     return best;
 }
 
-static int dw_tile(int N, int K, int M) { return dw_plan(M, N, K).tile; }
+static int dw_tile(int N, int K, int M, bool gather = false) { return dw_plan(M, N, K, gather).tile; }
 
 // Number of batch splits the wgrad kernel uses for (M,N,K); the workspace must hold
 // splits * round_up(K*N + N, 4) floats when splits > 1.
 DTF_API int dtf_dense_bwd_dw_splits(int M, int N, int K) { return dw_plan(M, N, K).splits; }
+// the same for the implicit-GEMM convolution's weight gradient (its gather kernels hold other numbers of blocks per CU)
+DTF_API int dtf_conv_wgrad_splits(int M, int N, int K) { return dw_plan(M, N, K, true).splits; }
 
 // dW[K,N] = X[M,K]^T . dZ[M,N];  db[N] = sum_m dZ[m,:]  (db may be null).
 DTF_API int dtf_dense_bwd_dw(const float* X, const float* dZ, float* dW, float* db, int M, int N, int K,
@@ -1395,8 +1446,8 @@ DTF_API int dtf_conv_gemm_wgrad(const float* Xpad, long long xpad_elems, const i
                                 const unsigned* masktab, hipStream_t stream) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     if (!gather_ok(rowtab, shift, C, K, false)) return -3;
-    const int splits = dtf_dense_bwd_dw_splits(M, N, K);
-    const int hint = dw_tile(N, K, M);
+    const int splits = dtf_conv_wgrad_splits(M, N, K);
+    const int hint = dw_tile(N, K, M, true);
     GemmArgs a = {};
     a.A = Xpad; a.B = dZ; a.ldb = N;
     a.M = K; a.N = N; a.K = M; a.ldc = N;

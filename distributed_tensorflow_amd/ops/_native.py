@@ -62,6 +62,7 @@ def kernels():
         "dtf_dense_bwd_dw_bf16": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
         "dtf_dense_bwd_dx": [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_f, c_p],
         "dtf_dense_bwd_dw_splits": [c_i, c_i, c_i],
+        "dtf_conv_wgrad_splits": [c_i, c_i, c_i],
         "dtf_dense_bwd_dw": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p],
         "dtf_mse_loss": [c_p, c_p, c_p, c_i, c_i, c_f, c_i, c_p, c_p],
         "dtf_softmax_xent": [c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_p, c_p],

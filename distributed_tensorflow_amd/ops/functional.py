@@ -170,10 +170,11 @@ def dense_backward_dx(dz, w, yprev=None, act_prev=ACT_NONE, scale_prev=1.0, out=
 
 
 def dense_dw_workspace_floats(M: int, N: int, K: int) -> int:
-    """Floats of scratch ``dense_backward_dw`` needs for a [M,K] x [M,N] weight gradient."""
+    """Floats of scratch ``dense_backward_dw`` (and ``conv_gemm_wgrad`` of the same product) needs for a
+    [M,K] x [M,N] weight gradient: one slab per batch split, for the larger of the two kernels' split counts."""
     if not nv.kernels_available():
         return 0
-    s = nv.kernels().dtf_dense_bwd_dw_splits(M, N, K)
+    s = max(nv.kernels().dtf_dense_bwd_dw_splits(M, N, K), nv.kernels().dtf_conv_wgrad_splits(M, N, K))
     return s * ((K * N + N + 3) // 4 * 4) if s > 1 else 0
 
 
