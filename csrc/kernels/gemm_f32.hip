@@ -588,7 +588,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
 // 80 (it took 82-88 on its own, which is five waves): the small-tile kernels - thin outputs, convolution gathers - hide
 // their load latency behind resident waves, not behind long MFMA runs.
 template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int EPI, bool GATHER = false>
-__global__ __launch_bounds__(256, (BM / WM == 32 && BN / WN == 32) ? 8 : 1) void gemm_f32_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(256, (BM / WM == 32 && BN / WN == 32) ? 6 : 1) void gemm_f32_kernel(const GemmArgs p) {
     static_assert(WM * WN == 4, "block is four waves");
     constexpr int TM = BM / WM / 32;
     constexpr int TN = BN / WN / 32;
