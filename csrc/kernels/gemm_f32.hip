@@ -48,6 +48,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 enum { EPI_FWD = 0, EPI_DX = 1, EPI_DW = 2 };
 
+
 struct GemmArgs {
     const float* A;
     const float* B;
@@ -584,11 +585,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
     }
 }
 
-// A wave that owns a single 32x32 sub-tile needs few registers; asking for six waves per SIMD keeps the compiler under
-// 80 (it took 82-88 on its own, which is five waves): the small-tile kernels - thin outputs, convolution gathers - hide
-// their load latency behind resident waves, not behind long MFMA runs.
+// Register budgets (waves per SIMD the compiler must leave room for).  A wave that owns a single 32x32 sub-tile: six
+// (80 registers; it took 82-88 on its own, which is five waves) - the small-tile kernels, thin outputs and convolution
+// gathers, hide their load latency behind resident waves, not behind long MFMA runs.  A wave with four sub-tiles: three
+// (168 registers instead of 195), so that with one LDS stage three 128x128 blocks share a CU instead of two (headline
+// step -1.6 %, widened MLP -3 %).  Eight waves for the small tiles (64 registers) spill and run 10-70 % slower.
 template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int EPI, bool GATHER = false>
-__global__ __launch_bounds__(256, (BM / WM == 32 && BN / WN == 32) ? 6 : 1) void gemm_f32_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(256, (BM / WM == 32 && BN / WN == 32) ? 6 : ((BM / WM) * (BN / WN) == 4096 ? 3 : 1))
+void gemm_f32_kernel(const GemmArgs p) {
     static_assert(WM * WN == 4, "block is four waves");
     constexpr int TM = BM / WM / 32;
     constexpr int TN = BN / WN / 32;
@@ -1009,16 +1013,24 @@ inline int env_dbg() {
     return v;
 }
 
+// One LDS stage instead of two (half the LDS per block: more resident blocks per CU, for a second barrier per k tile)?
+// Default: the convolution gathers and the 128x128 / 64x128 dense tiles (three instead of two, four instead of three
+// blocks per CU); the small dense tiles gain nothing.  DTF_GEMM_SINGLE=0/1 forces it for every kernel;
+// DTF_GEMM_SINGLE_TILES is a mask of dense tiles that take one stage (1: 128x128, 2: 64x128, 4: the others).
+inline int gemm_single_stage(int bm, int bn, bool gather) {
+    static const int forced = getenv("DTF_GEMM_SINGLE") ? atoi(getenv("DTF_GEMM_SINGLE")) : -1;
+    static const int mask = getenv("DTF_GEMM_SINGLE_TILES") ? atoi(getenv("DTF_GEMM_SINGLE_TILES")) : 3;
+    if (forced >= 0) return forced;
+    if (gather) return 1;
+    const int bit = (bm == 128 && bn == 128) ? 1 : ((bm == 64 && bn == 128) ? 2 : 4);
+    return (mask & bit) ? 1 : 0;
+}
+
 template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int EPI, bool GATHER = false>
 int launch_cfg(const GemmArgs& a, int splits, hipStream_t s) {
     using LoadA = TileLoader<BM, A_KC>;     // the gather loaders build the same LDS images
     using LoadB = TileLoader<BN, B_KC>;
-    // One LDS stage for the implicit-GEMM convolutions: their small tiles (N = 32 / 64 output channels) leave two
-    // resident blocks per CU with two stages, and the gather loaders' longer address arithmetic wants more waves to
-    // hide behind (measured on the MNIST CNN: 3.07 -> 3.00 ms/step; the dense layers of the MLP did not move).
-    // DTF_GEMM_SINGLE=0/1 overrides for every kernel.
-    static const int forced = getenv("DTF_GEMM_SINGLE") ? atoi(getenv("DTF_GEMM_SINGLE")) : -1;
-    const int single = forced >= 0 ? forced : (GATHER ? 1 : 0);
+    const int single = gemm_single_stage(BM, BN, GATHER);
     const size_t lds = (single ? 1 : 2) * (LoadA::LDS_FLOATS + LoadB::LDS_FLOATS) * sizeof(float);
     auto kern = gemm_f32_kernel<BM, BN, WM, WN, A_KC, B_KC, EPI, GATHER>;
     if (lds > 48 * 1024) {
@@ -1274,11 +1286,6 @@ DTF_API int dtf_dense_bwd_dx(const float* dZ, const float* W, float* dX, int M, 
 // reduction (each split writes, and the reducer reads, a K x N slab).
 struct DwPlan { int tile; int splits; };
 
-inline int gemm_single_stage(bool gather) {     // the rule of launch_cfg
-    static const int forced = getenv("DTF_GEMM_SINGLE") ? atoi(getenv("DTF_GEMM_SINGLE")) : -1;
-    return forced >= 0 ? forced : (gather ? 1 : 0);
-}
-
 // Workgroups of a wgrad kernel instantiation one CU holds at once, as the runtime computes it from the kernel's
 // registers and LDS (the 64x64 gather kernel: 82 registers -> 5 waves per SIMD, although its 17 KB of LDS would
 // allow nine).  The split count is chosen to fill exactly these slots: one block more and a second round starts
@@ -1289,7 +1296,7 @@ static int wgrad_resident_blocks() {
     if (cached) return cached;
     using LoadA = TileLoader<BM, false>;
     using LoadB = TileLoader<BN, false>;
-    const size_t lds = (gemm_single_stage(GATHER) ? 1 : 2) * (LoadA::LDS_FLOATS + LoadB::LDS_FLOATS) * sizeof(float);
+    const size_t lds = (gemm_single_stage(BM, BN, GATHER) ? 1 : 2) * (LoadA::LDS_FLOATS + LoadB::LDS_FLOATS) * sizeof(float);
     auto kern = gemm_f32_kernel<BM, BN, WM, WN, false, false, EPI_DW, GATHER>;
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
