@@ -48,10 +48,11 @@ def test_conv_as_gemm_matches_torch_conv2d(gpu_device, g):
     torch.testing.assert_close(y.cpu().view(ref.shape), ref, rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("C,pool", [(5, (2, 2)), (8, (2, 2)), (32, (3, 2))])     # scalar and 4-channel vector kernels
-def test_maxpool(gpu_device, C, pool):
+# scalar and 4-channel vector kernels; 2x2 windows tiling the image exactly take a kernel of their own backwards
+@pytest.mark.parametrize("C,pool,H", [(5, (2, 2), 9), (8, (2, 2), 9), (32, (3, 2), 9), (8, (2, 2), 8), (64, (2, 2), 14)])
+def test_maxpool(gpu_device, C, pool, H):
     gen = torch.Generator().manual_seed(2)
-    x = torch.randn(3, 9, 10, C, generator=gen)
+    x = torch.randn(3, H, 10, C, generator=gen)
     y_ref, a_ref = F.maxpool_forward(x, pool)
     y, a = F.maxpool_forward(x.to(gpu_device), pool)
     assert torch.equal(y.cpu(), y_ref) and torch.equal(a.cpu(), a_ref)
