@@ -46,6 +46,9 @@ print("block duration us: mean %.1f min %.1f max %.1f (main loop %.1f)" % ((ext 
 for n_on_cu in sorted(sizes):
     sel = [k for k, v in per.items() if len(v) == n_on_cu]
     print("  CUs with %d blocks: last exit mean %.1f us" % (n_on_cu, sum(max(float(ext[i]) for i in per[k]) for k in sel) / len(sel)))
+clock = float(t[:, 0].sum() / us.sum())       # cycles per us
+print("clock %.0f MHz; main loop %.1f us, epilogue %.1f us, entry -> loop start %.1f us" % (
+    clock, (t[:, 2] / clock).mean(), ((t[:, 0] - t[:, 2]) / clock).mean(), ((ext - ent) - us).mean()))
 busy = torch.tensor([sum(float(ext[i] - ent[i]) for i in v) for v in per.values()])
 print("per-CU sum of block durations / 2 slots: mean %.1f max %.1f us" % (busy.mean() / 2, busy.max() / 2))
 order = torch.argsort(ent)

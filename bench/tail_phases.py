@@ -23,14 +23,16 @@ def main():
     prof = torch.zeros(32, dtype=torch.int64, device=dev)
     step = torch.tensor([3], dtype=torch.int64, device=dev)
     args = _inputs(M, 10, dev)
-    for _ in range(3):
-        _run_tail(*args, 0.7, 77, step, 1.0 / 0.7)
+    keep = float(os.environ.get("TAIL_KEEP", "0.7"))       # 1.0: no dropout hashing in the h2 phase
+    for _ in range(int(os.environ.get("TAIL_WARM", "3"))):
+        _run_tail(*args, keep, 77, step, 1.0 / 0.7)
     lib.dtf_mlp_tail_set_profile_buffer(C.c_void_p(prof.data_ptr()))
-    _run_tail(*args, 0.7, 77, step, 1.0 / 0.7)
+    _run_tail(*args, keep, 77, step, 1.0 / 0.7)
     torch.cuda.synchronize()
     lib.dtf_mlp_tail_set_profile_buffer(None)
     t = prof.cpu().tolist()
     total = t[8] - t[0]
+    print("keep %.1f " % keep, end="")
     print("M=%d: second slab of workgroup 0 = %d shader-clock ticks" % (M, total))
     for i, name in enumerate(NAMES):
         d = t[i + 1] - t[i]

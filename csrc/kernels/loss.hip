@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
 
 inline int row_grid(int M) {
     int g = (M + 255) / 256;
-    if (g > 2048) g = 2048;
+    if (g > 512) g = 512;        // the kernels are grid-stride; every workgroup ends in same-address atomics (see dtf_mse_loss)
     return g < 1 ? 1 : g;
 }
 
@@ -207,8 +207,10 @@ DTF_API int dtf_mse_loss(const float* P, const float* Y, float* G, int M, int N,
                          int through_sigmoid, float* stats, hipStream_t stream) {
     if (M <= 0 || N <= 0) return 0;
     const long long total = (long long)M * N;
+    // one workgroup per CU at most: every workgroup ends with three atomic adds on the same three statistics words, and
+    // those serialise in L2 at ~14 ns each (2048 workgroups: 43 us of atomics behind 5 us of streaming)
     long long g = (total / 4 + 255) / 256;
-    if (g > 2048) g = 2048;
+    if (g > 256) g = 256;
     if (g < 1) g = 1;
     hipLaunchKernelGGL(mse_flat_kernel, dim3((int)g), dim3(256), 0, stream, P, Y, G, total, 1.0f / (float)N,
                        grad_scale, through_sigmoid, stats);
