@@ -137,8 +137,11 @@ __global__ void step_advance_kernel(long long* step_ptr, float* beta_powers, flo
 }
 
 inline int flat_grid(long long n) {
+    // Every workgroup ends with one returning atomic on the ticket word (~11 ns each, serialised in L2): models of a
+    // few million parameters are done streaming before 2048 tickets are, so they get 512 workgroups (two per CU).
     long long g = (n / 4 + 255) / 256;
-    if (g > 2048) g = 2048;
+    const long long cap = n > (1ll << 26) ? 2048 : 512;
+    if (g > cap) g = cap;
     return g < 1 ? 1 : (int)g;
 }
 
