@@ -10,8 +10,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from distributed_tensorflow_amd.ops import _native  # noqa: E402
 from tests.test_tail_gpu import _inputs, _run_tail  # noqa: E402
 
-NAMES = ["h1 slab -> LDS (+barrier)", "h2 = relu(h1 W2) + dropout (+barrier)", "logits (waves 0-3) (+barrier)",
-         "softmax / dz3 (wave 0) (+barrier)", "dW3, dz2 products, db3 (+barrier)", "dz2 mask in place (+barrier)",
+NAMES = ["h1 slab -> LDS (+barrier)", "h2 = relu(h1 W2) + dropout (+barrier)", "logits (16x16 tiles, all waves) (+barrier)",
+         "softmax / dz3 (+barrier)", "dW3, dz2 products, db3 (+barrier)", "dz2 mask in place (+barrier)",
          "dW2 + db2", "dz1 products + store (+barrier)"]
 
 

@@ -103,6 +103,47 @@ __device__ __forceinline__ void lds_tile_mma(f32x16& acc, const float* A, int ld
     lds_tile_mma_fill<A_KC, B_KC, K, 0>(acc, A, lda, m0, B, ldb, n0, lane, [](int) {});
 }
 
+// One 16x16 output tile on v_mfma_f32_16x16x4_f32 (half the cycles of a 32x32 tile for outputs that are only 16 wide:
+// class logits, their weight gradient).  Lane (i = lane & 15, q = lane >> 4) feeds row / column i; within a group of 16
+// k-values quarter q takes k = 4q .. 4q+3, one per MFMA step, so a k-contiguous operand is one 16-byte read per group.
+// C/D: column lane & 15, rows 4 * (lane >> 4) + r for register r = 0..3.
+template <bool A_KC, bool B_KC, int K>
+__device__ __forceinline__ void lds_tile16_mma(f32x4& acc, const float* A, int lda, int m0, const float* B, int ldb, int n0,
+                                               int lane) {
+    static_assert(K % 16 == 0, "k extent is a multiple of the 16-deep fragment group");
+    const int i = lane & 15, q = lane >> 4;
+    const float* pa = A_KC ? A + (m0 + i) * lda + 4 * q : A + (4 * q) * lda + m0 + i;
+    const float* pb = B_KC ? B + (n0 + i) * ldb + 4 * q : B + (4 * q) * ldb + n0 + i;
+    auto read = [&](int kk, f32x4& a, f32x4& b) {
+        if (A_KC) {
+            a = *reinterpret_cast<const f32x4*>(pa + kk);
+        } else {
+            const float* p = pa + kk * lda;
+            a[0] = p[0]; a[1] = p[lda]; a[2] = p[2 * lda]; a[3] = p[3 * lda];
+        }
+        if (B_KC) {
+            b = *reinterpret_cast<const f32x4*>(pb + kk);
+        } else {
+            const float* p = pb + kk * ldb;
+            b[0] = p[0]; b[1] = p[ldb]; b[2] = p[2 * ldb]; b[3] = p[3 * ldb];
+        }
+    };
+    f32x4 a[2], b[2];
+    read(0, a[0], b[0]);
+#pragma unroll
+    for (int g = 0; g < K / 16; ++g) {
+        const int cur = g & 1;
+        __builtin_amdgcn_sched_barrier(0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][0], b[cur][0], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + 1 < K / 16) read((g + 1) * 16, a[cur ^ 1], b[cur ^ 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 1; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][t], b[cur][t], acc, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 __device__ __forceinline__ void lds_zero(f32x16& a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) a[r] = 0.f;

@@ -93,8 +93,9 @@ __global__ __launch_bounds__(NT, 1) void mlp_tail_kernel(const TailArgs p) {
         const int rows = min(BM, p.M - slab * BM);
         ph.template issue<false>(p.H1 + (long long)slab * BM * H, (unsigned)rows * H * 4, H, tid);
     }
-    f32x16 g2[2], g3;
-    lds_zero(g2[0]); lds_zero(g2[1]); lds_zero(g3);
+    f32x16 g2[2];
+    f32x4 g3 = {0.f, 0.f, 0.f, 0.f};     // dW3 rows 16 * wave .. + 15 (C/D layout of the 16x16 MFMA)
+    lds_zero(g2[0]); lds_zero(g2[1]);
     float db2r = 0.f, db3r = 0.f, loss = 0.f, correct = 0.f, count = 0.f;
 
     for (; slab < nslabs; slab += gridDim.x) {
@@ -147,16 +148,17 @@ __global__ __launch_bounds__(NT, 1) void mlp_tail_kernel(const TailArgs p) {
         }
         __syncthreads();
         TAIL_PROF(2);
-        // ---- logits: two row tiles x two k-halves on waves 0..3; the halves meet in the softmax pass (fixed order)
-        if (wave < 4) {
-            const int rt = wave & 1, kh = wave >> 1;
-            f32x16 acc; lds_zero(acc);
-            lds_tile_mma<true, false, 64>(acc, sH2 + kh * 64, LH, rt * 32, sW3 + kh * 64 * LC, LC, 0, lane);
+        // ---- logits: the padded class dimension is 16 wide, so the products run as 16x16 tiles (half the matrix-pipe
+        //      time of 32x32 tiles with 16 dead columns): four row tiles x two k-halves on the eight waves; the halves
+        //      meet in the softmax pass (fixed order)
+        {
+            static_assert(CP == 16 && BM == 64 && NT == 512, "eight 16x16 logit jobs, one per wave");
+            const int rt = wave & 3, kh = wave >> 2;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            lds_tile16_mma<true, false, 64>(acc, sH2 + kh * 64, LH, rt * 16, sW3 + kh * 64 * LC, LC, 0, lane);
             float* dst = kh ? sPb : sPa;
-            if (li < CP) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) dst[(rt * 32 + lds_tile_row(r, h)) * LC + li] = acc[r];
-            }
+            for (int r = 0; r < 4; ++r) dst[(rt * 16 + 4 * (lane >> 4) + r) * LC + (lane & 15)] = acc[r];
         }
         __syncthreads();
         TAIL_PROF(3);
@@ -204,8 +206,9 @@ __global__ __launch_bounds__(NT, 1) void mlp_tail_kernel(const TailArgs p) {
         }
         __syncthreads();
         TAIL_PROF(4);
-        // ---- dW3 += h2^T dz3 (waves 0..3, input-unit block = wave); dz2 products (all waves), both read h2 / dz3
-        if (wave < 4) lds_tile_mma<false, false, BM>(g3, sH2, LH, wave * 32, sPa, LC, 0, lane);
+        // ---- dW3 += h2^T dz3 (16x16 tiles: hidden units 16 * wave .. + 15 on every wave); dz2 products; both read h2 / dz3
+        static_assert(H == 16 * (NT / 64), "one 16-unit block of dW3 per wave");
+        lds_tile16_mma<false, false, BM>(g3, sH2, LH, wave * 16, sPa, LC, 0, lane);
         f32x16 az; lds_zero(az);
         lds_tile_mma<true, true, CP>(az, sPa, LC, tm * 32, sW3, LC, tn * 32, lane);
         {   // db3: thread = (class tid & 15, row pair tid >> 4); the partial sums meet after the last slab
@@ -272,9 +275,9 @@ __global__ __launch_bounds__(NT, 1) void mlp_tail_kernel(const TailArgs p) {
         }
         sH1[tid0] = db2r;            // the slab buffers are free now: partial bias sums meet here
         sH1[NT + tid0] = db3r;
-        if (wave < 4 && li < C) {
+        if ((lane & 15) < C) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) base[H * H + H + (wave * 32 + lds_tile_row(r, h)) * C + li] = g3[r];
+            for (int r = 0; r < 4; ++r) base[H * H + H + (wave * 16 + 4 * (lane >> 4) + r) * C + (lane & 15)] = g3[r];
         }
         // loss / correct / example counts ride in the slab too: thousands of atomic adds on three addresses from
         // every wave of the grid would serialise in L2 for longer than the kernel runs
