@@ -38,6 +38,7 @@ def main():
         d = t[i + 1] - t[i]
         print("  %-44s %7d ticks  %5.1f %%" % (name, d, 100.0 * d / total))
     print("  SIMD of waves 0..7 of workgroup 0:", t[16:24])
+    print("  end of the h2 products per wave (ticks after the phase start):", [t[24 + w] - t[1] for w in range(8)])
     print("  inside the h2 phase (wave 0): products %d, epilogue %d, barrier wait %d ticks" % (t[9] - t[1], t[10] - t[9], t[2] - t[10]))
 
 

@@ -47,6 +47,21 @@ __device__ __forceinline__ float dtf_uniform(uint32_t key, unsigned long long id
     return (float)(r >> 8) * (1.0f / 16777216.0f);
 }
 
+// The dropout decision "dtf_uniform(key, idx) < keep" without leaving the integers: (float)(r >> 8) * 2^-24 < keep
+// <=> (r >> 8) < ceil(keep * 2^24) <=> r < ceil(keep * 2^24) << 8 (keep * 2^24 is exact in fp32).  Bit-identical
+// masks for half the vector instructions; valid for keep < 1.
+__device__ __forceinline__ uint32_t dtf_keep_threshold(float keep) {
+    return ((uint32_t)ceilf(keep * 16777216.0f)) << 8;
+}
+// element indices below 2^32 (the high word of dtf_uniform's index is zero and drops out)
+__device__ __forceinline__ bool dtf_keep32(uint32_t key, uint32_t idx, uint32_t threshold) {
+    return dtf_mix32(idx * 0x9E3779B1u + key) < threshold;
+}
+__device__ __forceinline__ bool dtf_keep64(uint32_t key, unsigned long long idx, uint32_t threshold) {
+    const uint32_t hi = (uint32_t)(idx >> 32);
+    return dtf_mix32(((uint32_t)idx * 0x9E3779B1u + key) ^ ((hi << 16) | (hi >> 16))) < threshold;
+}
+
 __device__ __forceinline__ float dtf_sigmoid(float z) { return 1.0f / (1.0f + __expf(-z)); }
 
 __device__ __forceinline__ float dtf_wave_sum(float v) {

@@ -70,6 +70,8 @@ __global__ __launch_bounds__(NT, 1) void mlp_tail_kernel(const TailArgs p) {
     const bool drop2 = p.keep2 < 1.0f;
     const float scale2 = drop2 ? 1.0f / p.keep2 : 1.0f;
     const uint32_t key2 = dtf_dropout_key(p.seed2, p.step_ptr);
+    const uint32_t thr2 = dtf_keep_threshold(p.keep2);
+    const bool idx32 = (long long)p.M * H < (1ll << 32);      // every element index of h2 fits 32 bits
     const int nslabs = (p.M + BM - 1) / BM;
 
     // ---- once per workgroup: weights and biases into LDS
@@ -128,16 +130,24 @@ __global__ __launch_bounds__(NT, 1) void mlp_tail_kernel(const TailArgs p) {
             float mult[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) mult[r] = 1.0f;
-            if (drop2) {
+            if (drop2 && idx32) {
+                // the hashing is what bounds this phase (vector issue, not the matrix pipe): 32-bit indices and an
+                // integer threshold keep it to a dozen instructions per element
+                const uint32_t e0 = (uint32_t)(row0 + tm * 32 + 4 * h) * (uint32_t)H + (uint32_t)col;
+                lds_tile_mma_fill<true, false, H, 14>(acc, sH1, LH, tm * 32, sW2, LH, tn * 32, lane, [&](int g) {
+                    mult[g] = dtf_keep32(key2, e0 + (uint32_t)(((g & 3) + 8 * (g >> 2)) * H), thr2) ? scale2 : 0.f;
+                });
+            } else if (drop2) {
                 const unsigned long long e0 = (unsigned long long)(row0 + tm * 32) * (unsigned)H + col;
                 lds_tile_mma_fill<true, false, H, 30>(acc, sH1, LH, tm * 32, sW2, LH, tn * 32, lane, [&](int g) {
-                    const float u = dtf_uniform(key2, e0 + (unsigned long long)lds_tile_row(g, h) * (unsigned)H);
-                    mult[g] = (u < p.keep2) ? scale2 : 0.f;
+                    mult[g] = dtf_keep64(key2, e0 + (unsigned long long)lds_tile_row(g, h) * (unsigned)H, thr2) ? scale2 : 0.f;
                 });
             } else {
                 lds_tile_mma<true, false, H>(acc, sH1, LH, tm * 32, sW2, LH, tn * 32, lane);
             }
             TAIL_PROF(9);
+            if (p.prof && blockIdx.x == 0 && lane == 0 && slab == (nslabs > (int)gridDim.x ? (int)gridDim.x : 0))
+                p.prof[24 + wave] = (long long)__builtin_readcyclecounter();     // every wave's end of the h2 products
             const float bv = sB2[col];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
