@@ -519,16 +519,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
     uint32_t key = 0;
     const bool drop = (EPI == EPI_FWD) && (p.keep < 1.0f);
     float inv_keep = 1.0f;
+    uint32_t keep_thr = 0;
     if (drop) {
         key = dtf_dropout_key(p.seed, p.step_ptr);
         inv_keep = 1.0f / p.keep;
+        keep_thr = dtf_keep_threshold(p.keep);
     }
     // A tile that lies entirely inside C (all of them except the last row / column of tiles) skips the per-element
     // bounds tests: with them the epilogue is several thousand instructions and costs about a tenth of a short-K GEMM.
     const float relu_floor = (p.act == ACT_RELU) ? 0.f : -INFINITY;
-    auto write_tile = [&](auto checked, auto simple) {
+    auto write_tile = [&](auto checked, auto simple, auto idx32) {
         constexpr bool CHECK = decltype(checked)::value;
         constexpr bool SIMPLE = decltype(simple)::value;   // forward: bias and ReLU / identity only; dgrad: ReLU mask or none
+        constexpr bool IDX32 = decltype(idx32)::value;     // every element index of C fits 32 bits (dropout hashing)
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -557,8 +560,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
                             if (p.act == ACT_SIGMOID) v = dtf_sigmoid(v);
                             else v = fmaxf(v, relu_floor);
                             if (drop) {
-                                const float u = dtf_uniform(key, (unsigned long long)(row0 + dr) * (unsigned)p.N + col);
-                                v = (u < p.keep) ? v * inv_keep : 0.f;
+                                const bool kept = IDX32 ? dtf_keep32(key, (uint32_t)(row0 + dr) * (uint32_t)p.N + (uint32_t)col, keep_thr)
+                                                        : dtf_keep64(key, (unsigned long long)(row0 + dr) * (unsigned)p.N + col, keep_thr);
+                                v = kept ? v * inv_keep : 0.f;
                             }
                         }
                     } else if (EPI == EPI_DX) {
@@ -577,11 +581,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
     };
     const bool simple = (EPI == EPI_FWD) ? (!drop && p.act != ACT_SIGMOID)
                                          : (EPI == EPI_DX ? (p.yprev == nullptr || p.act == ACT_RELU) : true);
+    const bool small_idx = (long long)p.M * p.N < (1ll << 32);
     if (m0 + BM <= p.M && n0 + BN <= p.N) {
-        if (simple) write_tile(std::false_type{}, std::true_type{});
-        else write_tile(std::false_type{}, std::false_type{});
+        if (simple) write_tile(std::false_type{}, std::true_type{}, std::true_type{});
+        else if (small_idx) write_tile(std::false_type{}, std::false_type{}, std::true_type{});
+        else write_tile(std::false_type{}, std::false_type{}, std::false_type{});
     } else {
-        write_tile(std::true_type{}, std::false_type{});
+        write_tile(std::true_type{}, std::false_type{}, std::false_type{});
     }
 }
 
@@ -1244,7 +1250,7 @@ __global__ __launch_bounds__(256) void reduce_fwd_slabs_kernel(const float* __re
             float v = acc[e] + (bias ? bias[col + e] : 0.f);
             if (act == ACT_RELU) v = fmaxf(v, 0.f);
             else if (act == ACT_SIGMOID) v = dtf_sigmoid(v);
-            if (drop) v = (dtf_uniform(key, (unsigned long long)(4 * i + e)) < keep) ? v * inv_keep : 0.f;   // index = row * N + col
+            if (drop) v = dtf_keep64(key, (unsigned long long)(4 * i + e), dtf_keep_threshold(keep)) ? v * inv_keep : 0.f;   // index = row * N + col
             acc[e] = v;
         }
         *reinterpret_cast<f32x4*>(Y + 4 * i) = acc;
