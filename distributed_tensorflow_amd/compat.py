@@ -590,13 +590,14 @@ class GraphEngine(ModelEngine):
                 feed["training"] = bool(v)
                 self._training = bool(v)
             elif isinstance(k, Tensor):
-                self._env[k] = _as_tensor(v, self.model.device)
+                self._env[k] = self._to_device(v)
             else:
                 feed[k] = v
+        # one transfer per fed value: the device tensors go down to the model engine as they are
         if "x" in feed:
-            self._env[self.input] = _as_tensor(feed["x"], self.model.device)
+            feed["x"] = self._env[self.input] = self._to_device(feed["x"])
         if "y" in feed:
-            self._env[self.labels] = _as_tensor(feed["y"], self.model.device)
+            feed["y"] = self._env[self.labels] = self._to_device(feed["y"])
         return super().run(fetch_struct, feed)
 
 

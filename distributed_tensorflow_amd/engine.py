@@ -26,6 +26,56 @@ from . import summary as summary_mod
 TRAIN_OP, LOSS, ACCURACY, GLOBAL_STEP = "train_op", "loss", "accuracy", "global_step"
 
 
+class FeedStager:
+    """Host arrays -> device tensors through pinned staging buffers.
+
+    One ring per (shape, dtype): ``depth`` pinned host buffers and as many device buffers.  ``put`` converts the array
+    into the next pinned buffer (one pass on the CPU: dtype conversion included), enqueues one non-blocking copy on the
+    current stream and records an event; a staging buffer is only rewritten after its event has completed, so a loop
+    that never reads anything back cannot overwrite a copy still in flight.  The device tensor handed out is reused
+    ``depth`` feeds of the same shape later - it is meant for values consumed within the step they are fed for.
+    Arrays above ``max_bytes`` are not staged (``put`` returns None): they are one-off transfers of whole data sets.
+    """
+
+    def __init__(self, device, depth: int = 4, max_bytes: int = 4 << 20):
+        self.device = device
+        self.depth = depth
+        self.max_bytes = max_bytes
+        self._rings = {}
+
+    @staticmethod
+    def _target_dtype(t: torch.Tensor):
+        # the rule of models.sequential._as_tensor: integer vectors are class ids, everything else is fp32
+        return torch.int64 if t.dtype in (torch.int64, torch.int32, torch.int16, torch.uint8) and t.dim() == 1 \
+            else torch.float32
+
+    def put(self, a):
+        t = torch.as_tensor(a)
+        if t.device.type != "cpu":
+            return None
+        dtype = self._target_dtype(t)
+        if t.numel() == 0 or t.numel() * (8 if dtype == torch.int64 else 4) > self.max_bytes:
+            return None
+        key = (tuple(t.shape), dtype)
+        ring = self._rings.get(key)
+        if ring is None:
+            ring = self._rings[key] = {
+                "host": [torch.empty(t.shape, dtype=dtype).pin_memory() for _ in range(self.depth)],
+                "dev": [torch.empty(t.shape, dtype=dtype, device=self.device) for _ in range(self.depth)],
+                "event": [None] * self.depth, "next": 0}
+        i = ring["next"]
+        ring["next"] = (i + 1) % self.depth
+        if ring["event"][i] is not None:
+            ring["event"][i].synchronize()
+        ring["host"][i].copy_(t)
+        ring["dev"][i].copy_(ring["host"][i], non_blocking=True)
+        ev = ring["event"][i]
+        if ev is None:
+            ev = ring["event"][i] = torch.cuda.Event()
+        ev.record()
+        return ring["dev"][i]
+
+
 class ModelEngine:
     def __init__(self, model, x_key="x", y_key="y", training_key="training"):
         self.model = model
@@ -163,8 +213,22 @@ class ModelEngine:
         return feed_dict.get(key, default)
 
     def _to_device(self, a, labels=False):
+        """A fed value on the model's device.  Host arrays of a session-style loop (``sess.run(train_op, {x: batch})``
+        at /root/reference/example.py:207-213) arrive once per step: a pageable host-to-device copy costs ~40 us here
+        (it synchronises the stream), so small feeds go through a ring of pinned staging buffers and one asynchronous
+        copy each (`FeedStager`); the tensors are consumed inside the same `run`."""
+        if isinstance(a, torch.Tensor) and a.device == self.model.device:
+            return a
+        dev = self.model.device
+        if dev.type == "cuda" and not isinstance(a, torch.Tensor):
+            stager = getattr(self, "_stager", None)
+            if stager is None:
+                stager = self._stager = FeedStager(dev)
+            t = stager.put(a)
+            if t is not None:
+                return t
         from .models.sequential import _as_tensor
-        return _as_tensor(a, self.model.device)
+        return _as_tensor(a, dev)
 
     def resolve(self, fetch):
         """Map a caller-level fetch object to an engine fetch name / callable (overridden by the graph engine)."""

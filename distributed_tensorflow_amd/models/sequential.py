@@ -34,6 +34,11 @@ def default_device() -> torch.device:
 def _as_tensor(a, device, dtype=None) -> torch.Tensor:
     if isinstance(a, torch.Tensor):
         t = a
+        # already where and what it should be (the per-step case of a session loop): skip the dispatcher round trip
+        if dtype is None and t.dtype in (torch.float32, torch.int64) and t.device.type == device.type \
+                and (device.index is None or t.device.index == device.index) and t.is_contiguous() \
+                and (t.dtype == torch.float32 or t.dim() == 1):
+            return t
     else:
         t = torch.as_tensor(a)
     if dtype is None:

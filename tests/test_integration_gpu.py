@@ -181,3 +181,26 @@ def test_learning_rate_change_recaptures_the_graph(gpu_device):
         assert m.optimizer.lr == pytest.approx(1e-3 * 0.09)
         flats.append(m.store.flat.clone())
     torch.testing.assert_close(flats[0], flats[1], rtol=1e-4, atol=1e-6)
+
+
+def test_host_feeds_through_pinned_ring_equal_device_feeds(gpu_device):
+    """Session-style steps fed with host arrays (staged through the pinned ring, never read back, so copies and
+    kernels of several steps are in flight) must train exactly as the same steps fed with device tensors."""
+    from distributed_tensorflow_amd.engine import TRAIN_OP, FeedStager, ModelEngine
+
+    def build():
+        m = xor_mlp()
+        m.compile(loss="mean_squared_error", optimizer="adam", metrics=["binary_rounded_accuracy"], device=gpu_device, seed=11)
+        return m, ModelEngine(m)
+
+    x, y, _, _ = get_data(50 * 12, val_set_size=0, seed=4)
+    x, y = x.numpy() if hasattr(x, "numpy") else x, y.numpy() if hasattr(y, "numpy") else y
+    m1, e1 = build()
+    m2, e2 = build()
+    for i in range(12):      # more steps than the ring is deep
+        xb, yb = x[i * 50:(i + 1) * 50], y[i * 50:(i + 1) * 50]
+        e1.run([TRAIN_OP], {"x": xb.astype("float64"), "y": yb})                      # host arrays, dtype converted on the way
+        e2.run([TRAIN_OP], {"x": torch.as_tensor(xb, dtype=torch.float32).to(gpu_device), "y": torch.as_tensor(yb).to(gpu_device)})
+    assert isinstance(e1._stager, FeedStager) and not hasattr(e2, "_stager")
+    assert torch.equal(m1.store.flat, m2.store.flat)
+    assert int(m1.store.global_step.item()) == 12
