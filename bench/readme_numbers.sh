@@ -1,7 +1,7 @@
+# Collects the numbers of the README table on one GPU into gpurun_out/readme_nums.txt: bash bench/readme_numbers.sh
 o=gpurun_out/readme_nums.txt; : > $o
 b() { echo "== $*" >> $o; timeout -k 10 300 python bench.py "$@" 2>/dev/null | tail -1 >> $o; }
 b --steps 20 --warmup 5
-cp /dev/null /dev/null
 b --steps 20 --warmup 5 --batch-per-gpu 32768 --eval 0
 b --steps 20 --warmup 5 --batch-per-gpu 65536 --eval 0
 b --steps 20 --warmup 5 --batch-per-gpu 131072 --eval 0
