@@ -65,3 +65,24 @@ def test_async_mode_self_launched():
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "async-ps2"
     assert sum(d["config"]["staleness_histogram_rank0"].values()) > 0
+
+
+def test_driver_style_torchrun_launch_on_cpu():
+    """The multi-GPU driver's command line (``python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...``), rehearsed with CPU ranks: the ranks join the
+    launcher's own store, rank 0 prints the one JSON line."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), BENCH, "--gpus", "2", "--device", "cpu", "--batch-per-gpu", "128", "--steps", "3",
+           "--warmup", "1", "--steady", "0.05", "--eval", "2"]
+    out = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["rccl_ranks"] == 2 and d["config"]["self_launched"] is False
+    assert sorted(r["rank"] for r in d["config"]["ranks"]) == [0, 1]
