@@ -1210,6 +1210,53 @@ __global__ __launch_bounds__(1024) void reduce_slabs_kernel(const float* __restr
     }
 }
 
+// The same sum for a handful of slabs: one thread per float4 column walks the slabs itself (the 16-group kernel above
+// leaves most of its waves idle below 16 slabs).  slab_stride and n_main are multiples of 4 here.
+__global__ __launch_bounds__(256) void reduce_few_slabs_kernel(const float* __restrict__ slabs, long long slab_stride, int splits,
+                                                               float* __restrict__ out_main, long long n_main,
+                                                               float* __restrict__ out_tail, long long n_total) {
+    const long long total4 = (n_total + 3) / 4;
+    for (long long i4 = (long long)blockIdx.x * 256 + threadIdx.x; i4 < total4; i4 += (long long)gridDim.x * 256) {
+        const long long i = i4 * 4;
+        if (i + 3 < n_total) {
+            f32x4 acc = *reinterpret_cast<const f32x4*>(slabs + i);
+            for (int s = 1; s < splits; ++s) acc += *reinterpret_cast<const f32x4*>(slabs + (long long)s * slab_stride + i);
+            if (i + 3 < n_main) {
+                *reinterpret_cast<f32x4*>(out_main + i) = acc;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const long long e = i + j;
+                    if (e < n_main) out_main[e] = acc[j];
+                    else out_tail[e - n_main] = acc[j];
+                }
+            }
+        } else {
+            for (int j = 0; j < 4 && i + j < n_total; ++j) {
+                const long long e = i + j;
+                float t = 0.f;
+                for (int s = 0; s < splits; ++s) t += slabs[(long long)s * slab_stride + e];
+                if (e < n_main) out_main[e] = t;
+                else out_tail[e - n_main] = t;
+            }
+        }
+    }
+}
+
+inline void launch_reduce_slabs(const float* slabs, long long stride, int splits, float* out_main, long long n_main,
+                                float* out_tail, long long n_total, hipStream_t stream) {
+    if (splits <= 8 && (stride & 3) == 0 && (n_main & 3) == 0 &&
+        ((reinterpret_cast<uintptr_t>(slabs) | reinterpret_cast<uintptr_t>(out_main)) & 15) == 0) {
+        long long blocks = ((n_total + 3) / 4 + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(reduce_few_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, slabs, stride, splits, out_main,
+                           n_main, out_tail, n_total);
+    } else {
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n_total + 255) / 256)), dim3(1024), 0, stream, slabs, stride, splits,
+                           out_main, n_main, out_tail, n_total);
+    }
+}
+
 }  // namespace
 
 // 0: fp32 GEMMs on the fp32 MFMA (default); 6 / 8 / 9: on the bf16 matrix cores from that many limb products
@@ -1430,9 +1477,7 @@ DTF_API int dtf_dense_bwd_dw(const float* X, const float* dZ, float* dW, float* 
     int rc = launch_gemm<false, false, EPI_DW>(a, eff_splits, stream, hint);
     if (rc) return rc;
     const long long n_total = db ? kn + N : kn;
-    const int blocks = (int)((n_total + 255) / 256);
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(1024), 0, stream, workspace, stride, eff_splits, dW,
-                       kn, db, n_total);
+    launch_reduce_slabs(workspace, stride, eff_splits, dW, kn, db, n_total, stream);
     DTF_CHECK_LAUNCH();
     return 0;
 }
@@ -1505,8 +1550,7 @@ DTF_API int dtf_conv_gemm_wgrad(const float* Xpad, long long xpad_elems, const i
     int rc = launch_gather<false, false, EPI_DW>(a, eff_splits, stream, hint);
     if (rc) return rc;
     const long long n_total = db ? kn + N : kn;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((int)((n_total + 255) / 256)), dim3(1024), 0, stream, workspace, stride,
-                       eff_splits, dW, kn, db, n_total);
+    launch_reduce_slabs(workspace, stride, eff_splits, dW, kn, db, n_total, stream);
     DTF_CHECK_LAUNCH();
     return 0;
 }
