@@ -74,6 +74,7 @@ __device__ __forceinline__ void lds_tile_mma_fill(f32x16& acc, const float* A, i
     };
     f32x4 a[2], b[2];
     read(0, a[0], b[0]);
+    constexpr int NREADS = (A_KC ? 1 : 4) + (B_KC ? 1 : 4);      // LDS read instructions per k-group
 #pragma unroll
     for (int g = 0; g < K / 8; ++g) {
         const int cur = g & 1;
@@ -81,17 +82,17 @@ __device__ __forceinline__ void lds_tile_mma_fill(f32x16& acc, const float* A, i
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][0], b[cur][0], acc, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         if (g + 1 < K / 8) read((g + 1) * 8, a[cur ^ 1], b[cur ^ 1]);
-        __builtin_amdgcn_sched_barrier(0);
         filler(g);
 #pragma unroll
         for (int t = 1; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][t], b[cur][t], acc, 0, 0, 0);
-        if (VALU_PER_GROUP > 0) {
-            // one MFMA, then a third of the filler's instructions, three times
+        // The next group's reads are dealt out over the gaps behind MFMAs 0, 1 and 2 (a burst of five to eight LDS
+        // reads in one gap costs the wave ~50 cycles of issue before its next MFMA; one or two per gap are free), the
+        // filler's vector instructions likewise.
 #pragma unroll
-            for (int t = 1; t < 4; ++t) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, (VALU_PER_GROUP + 2) / 3, 0);
-            }
+        for (int t = 1; t < 4; ++t) {
+            if (g + 1 < K / 8) __builtin_amdgcn_sched_group_barrier(0x100, (NREADS + 2) / 3, 0);
+            if (VALU_PER_GROUP > 0) __builtin_amdgcn_sched_group_barrier(0x002, (VALU_PER_GROUP + 2) / 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         }
     }
     __builtin_amdgcn_sched_barrier(0);
