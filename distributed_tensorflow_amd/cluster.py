@@ -183,28 +183,35 @@ def plan_devices(num_ps: int, num_workers: int, n_gpus: int, shared: bool = Fals
     """Which device every task of a one-node cluster computes on.
 
     ``n_gpus == 0``: everything on the CPU.  Otherwise worker ``i`` gets GPU ``i`` and ps task ``j`` GPU
-    ``num_workers + j``: RCCL accepts one rank per GPU, so no two tasks of a cluster may share one.  If the workers
-    alone do not fit, the cluster cannot run on this machine (``ValueError``).  If only the ps tasks do not fit
-    (1 ps + 8 workers on 8 GPUs), they get no GPU at all (``None``): they serve the control plane only and the
-    variables are owned by service threads inside the workers (``colocated``), sharded across the workers' HBMs.
-    ``shared=True`` (the gloo data plane: several ranks time-sharing one GPU on a test box) lifts the restriction and
-    wraps GPU indices around instead.
+    ``num_workers + j``: RCCL accepts one rank per GPU, so no two tasks of an RCCL cluster may share one.  If only
+    the ps tasks do not fit (1 ps + 8 workers on 8 GPUs), they get no GPU at all (``None``): they serve the control
+    plane only and the variables are owned by service threads inside the workers (``colocated``), sharded across the
+    workers' HBMs.  If the workers alone do not fit (the reference's default local run, 1 ps + 2 workers, on a
+    one-GPU machine) the plan is ``oversubscribed``: workers wrap around the GPUs, owners are colocated and exchange
+    data through hipIpc peer regions - which work between processes on one device - and any strategy that needs a
+    collective group falls back to gloo (``parallel.comm.pick_backend``), because RCCL cannot serve two ranks on one
+    GPU.  ``shared=True`` (``DTF_COMM_BACKEND=gloo``: several ranks time-sharing one GPU on a test box, ps tasks
+    included) wraps GPU indices for every task.
 
-    Returns ``{"worker": [...], "ps": [...], "colocated": bool}`` with ``"cpu"`` / ``"cuda:k"`` / ``None`` entries.
+    Returns ``{"worker": [...], "ps": [...], "colocated": bool, "oversubscribed": bool}`` with ``"cpu"`` /
+    ``"cuda:k"`` / ``None`` entries.
     """
     if n_gpus <= 0:
-        return {"worker": ["cpu"] * num_workers, "ps": ["cpu"] * num_ps, "colocated": num_ps == 0}
+        return {"worker": ["cpu"] * num_workers, "ps": ["cpu"] * num_ps, "colocated": num_ps == 0,
+                "oversubscribed": False}
     if shared:
         return {"worker": ["cuda:%d" % (i % n_gpus) for i in range(num_workers)],
-                "ps": ["cuda:%d" % ((num_workers + j) % n_gpus) for j in range(num_ps)], "colocated": num_ps == 0}
+                "ps": ["cuda:%d" % ((num_workers + j) % n_gpus) for j in range(num_ps)], "colocated": num_ps == 0,
+                "oversubscribed": num_workers + num_ps > n_gpus}
     if num_workers > n_gpus:
-        raise ValueError("%d worker tasks but %d GPU(s): RCCL needs one GPU per rank - start at most %d workers, or set "
-                         "DTF_COMM_BACKEND=gloo to let ranks time-share a GPU (rehearsal only)"
-                         % (num_workers, n_gpus, n_gpus))
+        return {"worker": ["cuda:%d" % (i % n_gpus) for i in range(num_workers)], "ps": [None] * num_ps,
+                "colocated": True, "oversubscribed": True}
     if num_workers + num_ps <= n_gpus:
         return {"worker": ["cuda:%d" % i for i in range(num_workers)],
-                "ps": ["cuda:%d" % (num_workers + j) for j in range(num_ps)], "colocated": num_ps == 0}
-    return {"worker": ["cuda:%d" % i for i in range(num_workers)], "ps": [None] * num_ps, "colocated": True}
+                "ps": ["cuda:%d" % (num_workers + j) for j in range(num_ps)], "colocated": num_ps == 0,
+                "oversubscribed": False}
+    return {"worker": ["cuda:%d" % i for i in range(num_workers)], "ps": [None] * num_ps, "colocated": True,
+            "oversubscribed": False}
 
 
 # --------------------------------------------------------------------------- server
@@ -297,6 +304,13 @@ class Server:
             n = torch.cuda.device_count()           # counting does not initialise the GPU runtime
         shared = os.environ.get("DTF_COMM_BACKEND", "") == "gloo"
         return plan_devices(self.num_ps, self.num_workers, n, shared)
+
+    def gpus_oversubscribed(self) -> bool:
+        """True when tasks of this cluster time-share a GPU (more workers than GPUs): RCCL cannot form a group
+        then, so collective strategies use gloo and asynchronous owners use hipIpc peer regions."""
+        if self.config.get("device"):
+            return False
+        return bool(self._device_plan()["oversubscribed"])
 
     def device(self):
         """The device this task computes on (see :func:`plan_devices`).  A ps task without a GPU of its own gets the

@@ -217,8 +217,6 @@ class ModelEngine:
         at /root/reference/example.py:207-213) arrive once per step: a pageable host-to-device copy costs ~40 us here
         (it synchronises the stream), so small feeds go through a ring of pinned staging buffers and one asynchronous
         copy each (`FeedStager`); the tensors are consumed inside the same `run`."""
-        if isinstance(a, torch.Tensor) and a.device == self.model.device:
-            return a
         dev = self.model.device
         if dev.type == "cuda" and not isinstance(a, torch.Tensor):
             stager = getattr(self, "_stager", None)

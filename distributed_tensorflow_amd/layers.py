@@ -383,7 +383,8 @@ class Conv2D(Layer):
             # windows of up to 32 positions: patches are gathered straight from the activations as they are stored and a
             # per-pixel bit set tells the loader which taps fall outside the image - no zero-padded copy is written
             # (for the MNIST CNN that removes three memory-bound passes per step); larger windows go through a copy
-            g = {"pt": pt, "pl": pl, "Hp": Hp, "Wp": Wp, "masked": kh * kw <= 32}
+            g = {"pt": pt, "pl": pl, "Hp": Hp, "Wp": Wp,
+                 "masked": self._masked_tables_fit(B, H, W, C, OH, OW, self.filters, kh, kw, self.need_input_grad)}
             if g["masked"]:
                 g["rowtab"], g["shift"], g["mask"] = F.conv_tables_unpadded(B, OH, OW, H, W, kh, kw, pt, pl, C, x.device)
                 if self._pool_in_epilogue_ok(OH, OW):
@@ -457,6 +458,18 @@ class Conv2D(Layer):
             F.dense_forward(cols, self.kernel.tensor.view(-1, Fo), bias, self.act, out=y)
         self._x, self._cols, self._y = x, cols, y
         return y.view(B, OH, OW, Fo)
+
+    @staticmethod
+    def _masked_tables_fit(B, H, W, C, OH, OW, N, kh, kw, need_input_grad) -> bool:
+        """May the implicit GEMM gather from the activations as stored (per-pixel bit set of in-image taps)?  Windows
+        of up to 32 positions only, and the gathered tensor - the input for forward / wgrad, the output gradient for
+        dgrad - must stay below 2^30 elements (the unpadded tables hold 30-bit element offsets; the padded-copy path
+        takes twice that)."""
+        if kh * kw > 32:
+            return False
+        if B * H * W * C >= (1 << 30):
+            return False
+        return not (need_input_grad and B * OH * OW * N >= (1 << 30))
 
     def _pool_in_epilogue_ok(self, OH: int, OW: int) -> bool:
         """May the 2x2 pooling that follows run in the epilogue of this layer's implicit GEMM?"""

@@ -331,9 +331,11 @@ class ParameterServerService:
         else:
             self.p2p.send(self.var[:self.n], wr, _TAG_PULL)
 
-    def _reply(self, worker: int, staleness: int, count_step: bool):
-        body = '{"version": %d, "global_step": %s, "staleness": %d}' % (
-            self.version, "%GS%" if count_step else "-1", staleness)
+    def _reply(self, worker: int, staleness: int, count_step: bool, seq: int = 0):
+        # `seq` echoes the request's sequence number: a worker that gave up on a slow reply (ControlTimeout, then
+        # in-process recovery) recognises the late answer to its abandoned request and drops it
+        body = '{"version": %d, "global_step": %s, "staleness": %d, "seq": %d}' % (
+            self.version, "%GS%" if count_step else "-1", staleness, seq)
         self.cp.add_set("global_step" if count_step else None, 1 if count_step else 0,
                         "%s/reply/%d/%d" % (self.ns, self.owner_index, worker), body.encode())
 
@@ -393,6 +395,7 @@ class ParameterServerService:
                 return
             w = req.get("worker")
             wr = self.worker_rank_of(w) if w is not None else None
+            seq = int(req.get("seq", 0))
             if op == "init":
                 if self.n:
                     src = self._incoming(w, wr, _TAG_INIT)
@@ -418,20 +421,20 @@ class ParameterServerService:
                 if self.region is not None:
                     if self.n:
                         self._send_params(w, wr)
-                    self._reply(w, st, self.owner_index == 0)
+                    self._reply(w, st, self.owner_index == 0, seq)
                 else:
                     # the reply first: the worker reads it after its receive has completed anyway, and a send
                     # that waits for the peer must not delay it
-                    self._reply(w, st, self.owner_index == 0)
+                    self._reply(w, st, self.owner_index == 0, seq)
                     if self.n:
                         self._send_params(w, wr)
             elif op == "pull":
                 if self.region is not None:
                     if self.n:
                         self._send_params(w, wr)
-                    self._reply(w, 0, False)
+                    self._reply(w, 0, False, seq)
                 else:
-                    self._reply(w, 0, False)
+                    self._reply(w, 0, False, seq)
                     if self.n:
                         self._send_params(w, wr)
             elif op == "save":
@@ -555,6 +558,7 @@ class AsyncPSStrategy:
         self.wait_seconds = 0.0       # host time blocked by the staleness bound
         self._service = None
         self._service_thread = None
+        self._seq = 0                 # sequence number of this worker's latest posting (echoed by the owners)
         self._cps: List[ControlClient] = []
         self._staging: Dict = {}
         self.region = None
@@ -581,13 +585,15 @@ class AsyncPSStrategy:
         return sum(c.calls for c, _ in self._distinct_cps())
 
     def _post(self, op: str, extra=None, owners=None):
-        """Queue one request per owner: one round trip per control server."""
+        """Queue one request per owner: one round trip per control server.  Every posting gets a new sequence number
+        that the owners echo in their replies."""
+        self._seq += 1
         for c, js in self._distinct_cps():
             items = []
             for j in js:
                 if owners is not None and j not in owners:
                     continue
-                req = {"op": op, "worker": self.worker_index}
+                req = {"op": op, "worker": self.worker_index, "seq": self._seq}
                 if extra is not None:
                     req.update(extra(j) if callable(extra) else extra)
                 items.append(("%s/req/%d" % (self.ns, j), req))
@@ -598,9 +604,25 @@ class AsyncPSStrategy:
         """The owners' replies to this worker's last requests, in owner order: one round trip per control server."""
         reps: List[Optional[dict]] = [None] * self.num_owners
         for c, js in self._distinct_cps():
-            got = c.take_many_json(["%s/reply/%d/%d" % (self.ns, j, self.worker_index) for j in js], timeout_s=self.timeout_s)
-            for j, r in zip(js, got):
-                reps[j] = r
+            pending = list(js)
+            while pending:
+                try:
+                    got = c.take_many_json(["%s/reply/%d/%d" % (self.ns, j, self.worker_index) for j in pending],
+                                           timeout_s=self.timeout_s)
+                except ControlTimeout as e:
+                    if self.p2p is not None:
+                        # send/recv pairs with that owner are now unmatched: nothing in this process can repair the
+                        # stream order of the communicator, so this is the loss of a task, not a transient fault
+                        from ..failure import ClusterLostError
+                        raise ClusterLostError("no reply from a parameter server within %.0f s" % self.timeout_s) from e
+                    raise
+                late = []
+                for j, r in zip(pending, got):
+                    if int(r.get("seq", self._seq)) == self._seq:
+                        reps[j] = r
+                    else:
+                        late.append(j)       # the answer to a request this worker abandoned: take the next one
+                pending = late
         self._check_service()
         return reps
 

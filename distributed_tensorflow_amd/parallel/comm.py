@@ -27,6 +27,9 @@ def env_local_rank() -> int:
     return int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
 
 
+_WARNED_SHARED = False
+
+
 def pick_backend(device=None) -> str:
     """``nccl`` (RCCL) for GPU tensors, ``gloo`` for CPU.  ``DTF_COMM_BACKEND=gloo`` forces gloo for GPU tensors too:
     RCCL refuses two ranks on one device, so several ranks time-sharing a single GPU (the one-GPU test box) talk
@@ -34,6 +37,15 @@ def pick_backend(device=None) -> str:
     forced = os.environ.get("DTF_COMM_BACKEND")
     if forced:
         return forced
+    from ..cluster import current_server
+    srv = current_server()
+    if srv is not None and device is not None and torch.device(device).type == "cuda" and srv.gpus_oversubscribed():
+        global _WARNED_SHARED
+        if not _WARNED_SHARED:
+            _WARNED_SHARED = True
+            print("WARNING: %d worker tasks share %d GPU(s); RCCL needs one GPU per rank, so the collectives of this "
+                  "run go over gloo (staged through host memory)" % (srv.num_workers, torch.cuda.device_count()), flush=True)
+        return "gloo"
     if device is not None:
         return "nccl" if torch.device(device).type == "cuda" else "gloo"
     return "nccl" if torch.cuda.is_available() else "gloo"

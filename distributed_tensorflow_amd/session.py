@@ -453,6 +453,7 @@ class MonitoredSession:
     def check_health(self):
         """Raise ``ClusterLostError`` if the failure detector of this session has lost a task (for loops that do not
         go through ``run``, such as ``model.fit`` inside a session)."""
+        self._step_cache = None       # training outside run() (model.fit) has moved the counter since the last read
         for h in self.hooks:
             d = getattr(h, "detector", None)
             if d is not None:
@@ -461,6 +462,9 @@ class MonitoredSession:
     def close(self, run_end_hooks: bool = True):
         if self._closed:
             return
+        # training that never went through run() (model.fit inside the session) has advanced the counter: the end
+        # hooks - the final checkpoint's name among them - must see the real step, not the one cached at creation
+        self._step_cache = None
         if run_end_hooks:
             for h in self.hooks:
                 h.end(self)

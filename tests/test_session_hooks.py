@@ -196,3 +196,17 @@ def test_step_latency_percentiles_and_comm_time(tmp_path):
     for e in sm.read_events(path):
         tags |= set(e.get("scalars", {}))
     assert {"step_latency_ms/p99", "comm_ms/step"} <= tags
+
+
+def test_fit_inside_session_names_final_checkpoint_by_trained_step(tmp_path):
+    """`model.fit` inside a session never passes through `run` (/root/reference/example2.py:189-200): the end hooks
+    must still see the real step, so the final checkpoint is `model.ckpt-<steps trained>`."""
+    m, eng = make()
+    d = str(tmp_path)
+    xt, yt = DATA[0], DATA[1]
+    with ss.MonitoredTrainingSession(engine=eng, checkpoint_dir=d, save_summaries_steps=None, log_step_count_steps=None) as sess:
+        assert sess.global_step_value() == 0
+        m.fit(xt, yt, epochs=2, batch_size=50, verbose=0, shuffle=False)
+        sess.check_health()
+        assert sess.global_step_value() == 20
+    assert latest_checkpoint(d).endswith("model.ckpt-20")
