@@ -40,7 +40,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 # must be in place before the first GPU call of the process: RCCL's intra-node transport needs dmabuf IPC here
-os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+if os.environ.get("DTF_KEEP_IPC_MODE") != "1":
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 # CPU proxy of the reference workload (examples/s, 1 thread, PyTorch CPU): the denominator of "vs_baseline"
 BASELINE_EXAMPLES_PER_SEC = 37700.0
@@ -101,72 +102,263 @@ def _free_port() -> int:
     return port
 
 
-def self_launch(args, argv) -> int:
-    """Start ``args.gpus`` rank processes of this script, wait for them, relay rank 0's JSON line.
+# How the rank processes of a multi-GPU run bring up their process group, in the order tried.  A value of None
+# removes the variable from the rank's environment.  The first set whose every rank passes the pre-flight check
+# (group initialised, one all-reduce verified against its analytic sum) runs the benchmark; its name is printed as
+# ``config.launch_variant``.  The last one stages the collectives through host memory over gloo: slow, but a
+# labelled measurement instead of none.
+LAUNCH_VARIANTS = {
+    "cuda": [
+        ("rccl-eager-init", {}),
+        ("rccl-lazy-init", {"DTF_PG_LAZY_INIT": "1"}),
+        ("rccl-lazy-init-default-ipc", {"DTF_PG_LAZY_INIT": "1", "DTF_KEEP_IPC_MODE": "1",
+                                        "HSA_ENABLE_IPC_MODE_LEGACY": None}),
+        ("gloo-host-staged", {"DTF_COMM_BACKEND": "gloo"}),
+    ],
+    "cpu": [("gloo-cpu", {}), ("gloo-cpu-second-try", {})],
+}
+INIT_TIMEOUT_S = float(os.environ.get("DTF_BENCH_INIT_TIMEOUT", "420"))
 
-    Runs before this process has imported torch or made any GPU call; the children are fresh processes (never an exec
-    from a process that holds the GPU).  Returns the exit code: 0 only if every rank exited 0 and rank 0 printed a line.
-    """
-    n = args.gpus
-    port = _free_port()
-    procs = []
-    for r in range(n):
-        env = dict(os.environ)
-        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
-                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "DTF_BENCH_SELF_LAUNCHED": "1"})
-        env.setdefault("OMP_NUM_THREADS", "2")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
-    failed = None
-    try:
-        # rank 0's stdout is read to its end first: it ends when rank 0 exits (or is ended below through a failing peer)
-        import threading
-        lines = []
 
-        def pump():
-            for line in procs[0].stdout:
-                lines.append(line.rstrip("\n"))
+class _LocalCoordinator:
+    """One supervisor owns every rank (``python bench.py --gpus N`` started plainly)."""
 
-        t = threading.Thread(target=pump, daemon=True)
-        t.start()
-        pending = set(range(n))
-        while pending and failed is None:
-            for r in sorted(pending):
-                rc = procs[r].poll()
-                if rc is None:
-                    continue
-                pending.discard(r)
-                if rc != 0:
-                    failed = (r, rc)
-                    break
+    def __init__(self, world):
+        self.world = world
+        self._fail = set()
+        self._ok = {}
+
+    def port(self, v):
+        return _free_port()
+
+    def report_fail(self, v):
+        self._fail.add(v)
+
+    def failed(self, v):
+        return v in self._fail
+
+    def report_ok(self, v):
+        self._ok[v] = self._ok.get(v, 0) + 1
+
+    def all_ok(self, v):
+        return self._ok.get(v, 0) >= self.world
+
+    def all_down(self, v, timeout_s=60.0):
+        return True
+
+
+class _StoreCoordinator:
+    """One supervisor per rank (the driver's ``python -m torch.distributed.run ... bench.py``): the supervisors agree
+    through the launcher's own TCP store (they are clients of it; no GPU call is involved)."""
+
+    def __init__(self, rank, world):
+        import datetime
+        from torch.distributed import TCPStore
+        self.rank, self.world = rank, world
+        agent = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "").lower() in ("1", "true")
+        self.store = TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]), world_size=None,
+                              is_master=(rank == 0 and not agent), timeout=datetime.timedelta(seconds=600),
+                              wait_for_workers=False)
+        self.ns = "dtf_bench/%s/" % os.environ.get("TORCHELASTIC_RUN_ID", "run")
+
+    def port(self, v):
+        key = self.ns + "v%d/port" % v
+        if self.rank == 0:
+            self.store.set(key, str(_free_port()))
+        return int(self.store.get(key).decode())
+
+    def report_fail(self, v):
+        self.store.set(self.ns + "v%d/fail" % v, "1")
+
+    def failed(self, v):
+        return bool(self.store.check([self.ns + "v%d/fail" % v]))
+
+    def report_ok(self, v):
+        self.store.add(self.ns + "v%d/ok" % v, 1)
+
+    def all_ok(self, v):
+        return self.store.add(self.ns + "v%d/ok" % v, 0) >= self.world
+
+    def all_down(self, v, timeout_s=60.0):
+        key = self.ns + "v%d/down" % v
+        self.store.add(key, 1)
+        deadline = time.time() + timeout_s
+        while time.time() < deadline:
+            if self.store.add(key, 0) >= self.world:
+                return True
             time.sleep(0.05)
-        t.join(timeout=5)
-    finally:
-        # end exactly the processes started above (a rank that failed leaves its peers blocked in a collective)
-        for p in procs:
-            if p.poll() is None:
-                p.terminate()
-        deadline = time.time() + 10
-        for p in procs:
-            try:
-                p.wait(timeout=max(0.1, deadline - time.time()))
-            except subprocess.TimeoutExpired:
-                p.kill()
-    if failed is not None:
-        sys.stderr.write("bench.py: rank %d of %d exited with status %d; no result\n" % (failed[0], n, failed[1]))
-        return failed[1] if failed[1] > 0 else 1
-    result = [l for l in lines if l.startswith("{")]
-    for l in lines:
-        if not l.startswith("{"):
-            sys.stderr.write(l + "\n")
-    if not result:
-        sys.stderr.write("bench.py: rank 0 printed no result line\n")
-        return 1
-    print(result[-1], flush=True)
-    return 0
+        return False
+
+
+def _stop(procs):
+    """End exactly the processes started here (a rank that failed leaves its peers blocked in a collective)."""
+    for p in procs:
+        if p.poll() is None:
+            p.terminate()
+    deadline = time.time() + 10
+    for p in procs:
+        try:
+            p.wait(timeout=max(0.1, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.wait()
+
+
+def supervise(args, argv, my_ranks, coord, self_launched) -> int:
+    """Run the rank processes ``my_ranks`` of a ``coord.world``-rank job as fresh child processes and relay rank 0's
+    JSON line.  The supervisor never touches a GPU, and a rank that has is never re-executed: when any rank of the job
+    fails before the whole group has passed its pre-flight check, every supervisor ends its children and starts a new
+    set under the next entry of ``LAUNCH_VARIANTS``.  Returns the exit code: 0 only if every rank exited 0 and rank 0
+    printed a line (the reference starts N worker processes by hand, /root/reference/example.py:124-141)."""
+    import tempfile
+    import threading
+    import signal
+    world = coord.world
+    variants = LAUNCH_VARIANTS[args.device]
+    if args.device == "cuda" and os.environ.get("DTF_COMM_BACKEND"):
+        variants = [("forced-%s" % os.environ["DTF_COMM_BACKEND"], {})]     # the caller chose the data plane
+
+    def _terminated(signum, frame):      # a launcher above ends its ranks with SIGTERM: take the children along
+        raise SystemExit(128 + signum)
+
+    signal.signal(signal.SIGTERM, _terminated)
+    local_rank = {r: (int(os.environ.get("LOCAL_RANK", r)) if len(my_ranks) == 1 else r) for r in my_ranks}
+    only = os.environ.get("DTF_BENCH_LAUNCH_VARIANT")
+    status_dir = tempfile.mkdtemp(prefix="dtf_bench_")
+    last_rc = 1
+    for v, (name, overrides) in enumerate(variants):
+        if only and name != only:
+            continue
+        port = coord.port(v)
+        procs, lines = [], []
+        for r in my_ranks:
+            env = dict(os.environ)
+            env.pop("TORCHELASTIC_USE_AGENT_STORE", None)    # the children's rank 0 serves their own store on ``port``
+            env.update({"RANK": str(r), "LOCAL_RANK": str(local_rank[r]), "WORLD_SIZE": str(world),
+                        "LOCAL_WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "DTF_BENCH_CHILD": "1",
+                        "DTF_BENCH_SELF_LAUNCHED": "1" if self_launched else "0", "DTF_BENCH_VARIANT": name,
+                        "DTF_BENCH_VARIANT_INDEX": str(v), "DTF_BENCH_STATUS": os.path.join(status_dir, "v%d_r%d" % (v, r))})
+            for k, val in overrides.items():
+                if val is None:
+                    env.pop(k, None)
+                else:
+                    env[k] = val
+            env.setdefault("OMP_NUM_THREADS", "2")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                          stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+        pump = None
+        if 0 in my_ranks:
+            out0 = procs[my_ranks.index(0)].stdout
+
+            def _pump(stream=out0, sink=lines):
+                for line in stream:
+                    sink.append(line.rstrip("\n"))
+
+            pump = threading.Thread(target=_pump, daemon=True)
+            pump.start()
+        reported, group_ok, failed = set(), False, None
+        t_start = time.time()
+        try:
+            pending = set(range(len(procs)))
+            while pending:
+                for i in sorted(pending):
+                    rc = procs[i].poll()
+                    if rc is None:
+                        continue
+                    pending.discard(i)
+                    if rc != 0 and failed is None:
+                        failed = (my_ranks[i], rc)
+                if not group_ok:
+                    for i, r in enumerate(my_ranks):
+                        if i not in reported and os.path.exists(os.path.join(status_dir, "v%d_r%d" % (v, r))):
+                            reported.add(i)
+                            coord.report_ok(v)
+                    group_ok = coord.all_ok(v)
+                if failed is None and (coord.failed(v) or (not group_ok and time.time() - t_start > INIT_TIMEOUT_S)):
+                    failed = (-1, 1)
+                if failed is not None:
+                    # the pre-flight check ends with a collective, so one rank past it means every rank got through it
+                    group_ok = group_ok or len(reported) > 0
+                    coord.report_fail(v)
+                    break
+                time.sleep(0.05)
+        finally:
+            _stop(procs)
+        if pump is not None:
+            pump.join(timeout=5)
+        if failed is None:
+            result = [l for l in lines if l.startswith("{")]
+            for l in lines:
+                if not l.startswith("{"):
+                    sys.stderr.write(l + "\n")
+            if 0 in my_ranks:
+                if not result:
+                    sys.stderr.write("bench.py: rank 0 printed no result line\n")
+                    return 1
+                print(result[-1], flush=True)
+            return 0
+        last_rc = failed[1] if failed[1] > 0 else 1
+        if last_rc == 78:        # EXIT_CONFIG
+            return last_rc
+        if group_ok:
+            # every rank had passed the pre-flight check: this is a failure of the run itself, not of its bring-up
+            sys.stderr.write("bench.py: rank %d of %d exited with status %d; no result\n" % (failed[0], world, failed[1]))
+            return last_rc
+        sys.stderr.write("bench.py: launch variant '%s' did not bring up all %d ranks (%s)%s\n"
+                         % (name, world, "rank %d exited with status %d" % failed if failed[0] >= 0 else "a peer failed or timed out",
+                            "; trying the next one" if v + 1 < len(variants) and not only else ""))
+        coord.all_down(v)
+    sys.stderr.write("bench.py: no launch variant brought up %d ranks; no result\n" % world)
+    return last_rc
 
 
 # ----------------------------------------------------------------------------------------------- one rank
+def _preflight(torch, dist, dev, on_gpu, backend, rank, world):
+    """Before anything is timed: one all-reduce of the flat-gradient size of the headline model (118 282 floats,
+    473 KB) checked against its analytic sum in every rank, the peer-access matrix and the RCCL version.  Raises if
+    the sum is wrong, so a broken transport ends the bring-up (and the supervisor tries its next variant)."""
+    n = 118282
+    idx = torch.arange(n, dtype=torch.float32, device=dev)
+    t = (idx % 97.0) * float(rank + 1)
+    if backend == "gloo" and on_gpu:
+        h = t.cpu()
+        dist.all_reduce(h)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t)
+    want = (idx % 97.0) * float(world * (world + 1) // 2)
+    err = float((t - want).abs().max().item())
+    if err != 0.0:
+        raise SystemExit("bench.py: pre-flight all-reduce over %s is wrong by %g in rank %d" % (backend, err, rank))
+    info = {"allreduce_473KB_max_abs_err": err, "backend": backend}
+    if on_gpu:
+        ndev = torch.cuda.device_count()
+        me = dev.index or 0
+        row = [bool(j == me or torch.cuda.can_device_access_peer(me, j)) for j in range(min(ndev, world))]
+        rows = [None] * world
+        dist.all_gather_object(rows, row)
+        info["peer_access"] = rows
+        if backend == "nccl":
+            try:
+                info["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+            except Exception as e:      # reporting only
+                info["rccl_version"] = "unknown (%s)" % type(e).__name__
+        info["hsa_enable_ipc_mode_legacy"] = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")
+    if backend == "nccl":
+        dist.barrier(device_ids=[dev.index])
+    else:
+        dist.barrier()
+    return info
+
+
+EXIT_CONFIG = 78     # a rank ended because the request cannot be met on this machine: no other launch variant will help
+
+
+def _config_error(msg):
+    sys.stderr.write(msg + "\n")
+    sys.exit(EXIT_CONFIG)
+
+
 def run_rank(args) -> None:
     if args.allreduce == "p2p":
         os.environ["DTF_ALLREDUCE"] = "p2p"
@@ -189,11 +381,11 @@ def run_rank(args) -> None:
         # counting devices does not initialise the GPU runtime, so this check is safe in every rank before rendezvous
         ndev = torch.cuda.device_count()
         if ndev < 1:
-            raise SystemExit("bench.py needs a GPU (none visible)")
+            _config_error("bench.py needs a GPU (none visible)")
         backend = pick_backend(torch.device("cuda", 0))
         if world > ndev and backend == "nccl":
-            raise SystemExit("bench.py: --gpus %d but this machine exposes %d GPU(s); RCCL needs one GPU per rank "
-                             "(DTF_COMM_BACKEND=gloo rehearses several ranks on one GPU)" % (world, ndev))
+            _config_error("bench.py: --gpus %d but this machine exposes %d GPU(s); RCCL needs one GPU per rank "
+                          "(DTF_COMM_BACKEND=gloo rehearses several ranks on one GPU)" % (world, ndev))
         dev = torch.device("cuda", local_rank % ndev)
         torch.cuda.set_device(dev)
         _native.kernels()  # fail loudly if the HIP library is missing
@@ -205,6 +397,12 @@ def run_rank(args) -> None:
     def sync_device():
         if on_gpu:
             torch.cuda.synchronize()
+
+    # test hook: "v:r[,v:r...]" makes rank r of launch variant v die while the group comes up
+    inject = os.environ.get("DTF_BENCH_INJECT_INIT_FAIL", "")
+    if inject and "%s:%d" % (os.environ.get("DTF_BENCH_VARIANT_INDEX", "-"), rank) in inject.split(","):
+        sys.stderr.write("bench.py: injected bring-up failure in rank %d\n" % rank)
+        os._exit(86)
 
     strategy = None
     multi = world > 1 or bool(args.single_rank_collectives)
@@ -230,6 +428,9 @@ def run_rank(args) -> None:
             init_process_group(backend, device=dev if on_gpu else None)
         strategy = SyncReplicasStrategy(Communicator(), bucket_bytes=int(args.bucket_mb * (1 << 20)))
     data_plane = dist.get_backend() if dist.is_initialized() else None      # what barriers / timing reductions use
+    preflight = _preflight(torch, dist, dev, on_gpu, data_plane, rank, world) if world > 1 else None
+    if os.environ.get("DTF_BENCH_STATUS"):
+        open(os.environ["DTF_BENCH_STATUS"], "w").write("ok\n")     # tells the supervisor that this rank is up
 
     B = args.batch_per_gpu or DEFAULT_BATCH[args.model]
     metrics = ["accuracy"]
@@ -432,7 +633,10 @@ def run_rank(args) -> None:
                        "steady_warmup_steps": steady_windows * 10,
                        "data_plane": ("peer regions (%s), control plane over TCP" % ("hipIpc over xGMI" if on_gpu else "shared memory")
                                       if args.mode == "async" else {"nccl": "rccl"}.get(data_plane, data_plane)),
-                       "rccl_ranks": group_size,
+                       # the size of the RCCL communicator; null whenever the collectives did not go over RCCL
+                       "rccl_ranks": group_size if data_plane == "nccl" else None,
+                       "backend": data_plane, "group_ranks": group_size,
+                       "launch_variant": os.environ.get("DTF_BENCH_VARIANT"), "preflight": preflight,
                        "self_launched": os.environ.get("DTF_BENCH_SELF_LAUNCHED") == "1",
                        "ranks": ranks,
                        **({"device": "cpu (plumbing rehearsal, not a benchmark)"} if not on_gpu else {}),
@@ -451,8 +655,20 @@ def main(argv=None):
     args = parse_args(argv)
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
-    if args.gpus > 1 and not _under_launcher():
-        sys.exit(self_launch(args, argv))
+    if args.gpus > 1 and os.environ.get("DTF_BENCH_CHILD") != "1":
+        # this process only supervises: the ranks are fresh children, so a failed bring-up can be tried again another
+        # way without ever re-using a process that has touched a GPU
+        if _under_launcher():
+            rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+            if world != args.gpus:
+                raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE); they must agree"
+                                 % (args.gpus, world))
+            sys.exit(supervise(args, argv, [rank], _StoreCoordinator(rank, world), self_launched=False))
+        sys.exit(supervise(args, argv, list(range(args.gpus)), _LocalCoordinator(args.gpus), self_launched=True))
+    if os.environ.get("DTF_BENCH_CHILD") == "1":
+        import ctypes
+        import signal
+        ctypes.CDLL(None, use_errno=True).prctl(1, int(signal.SIGKILL), 0, 0, 0)    # PR_SET_PDEATHSIG: never outlive the supervisor
     run_rank(args)
 
 

@@ -63,13 +63,15 @@ def init_process_group(backend: Optional[str] = None, rank: Optional[int] = None
         backend = pick_backend(device)
     addr = master_addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
     port = master_port or int(os.environ.get("MASTER_PORT", "29500"))
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC is what the host driver supports
+    if os.environ.get("DTF_KEEP_IPC_MODE") != "1":
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC is what the host driver supports
     kwargs = {}
     if backend == "nccl":
         if device is None:
             device = torch.device("cuda", env_local_rank() % max(torch.cuda.device_count(), 1))
         torch.cuda.set_device(device)
-        kwargs["device_id"] = device
+        if os.environ.get("DTF_PG_LAZY_INIT") != "1":
+            kwargs["device_id"] = device     # eager communicator creation; lazy = at the first collective
     dist.init_process_group(backend=backend, init_method="tcp://%s:%d" % (addr, port), rank=rank,
                             world_size=world_size, timeout=datetime.timedelta(seconds=timeout_s), **kwargs)
     return dist.group.WORLD

@@ -38,7 +38,10 @@ def test_self_launch_runs_every_rank(world):
     assert d["n_gpus"] == world and d["steps"] == 3 and d["warmup"] == 1
     c = d["config"]
     assert c["parallelism"] == "dp%d" % world and c["global_batch"] == 128 * world
-    assert c["rccl_ranks"] == world and c["self_launched"] is True
+    # the collectives went over gloo here: the RCCL field must stay empty, the group size is reported separately
+    assert c["rccl_ranks"] is None and c["backend"] == "gloo" and c["group_ranks"] == world
+    assert c["self_launched"] is True and c["launch_variant"] == "gloo-cpu"
+    assert c["preflight"]["allreduce_473KB_max_abs_err"] == 0.0
     assert sorted(r["rank"] for r in c["ranks"]) == list(range(world))
     assert len({r["pid"] for r in c["ranks"]}) == world          # really N processes
     assert c["test_acc"] is not None and 0.0 <= c["test_acc"] <= 1.0
@@ -84,5 +87,44 @@ def test_driver_style_torchrun_launch_on_cpu():
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["config"]["rccl_ranks"] == 2 and d["config"]["self_launched"] is False
+    assert d["n_gpus"] == 2 and d["config"]["group_ranks"] == 2 and d["config"]["self_launched"] is False
+    assert d["config"]["rccl_ranks"] is None and d["config"]["backend"] == "gloo"
     assert sorted(r["rank"] for r in d["config"]["ranks"]) == [0, 1]
+
+
+def test_failed_bring_up_is_tried_again_with_fresh_ranks():
+    """Rank 1 of the first launch variant dies while the group comes up: the supervisor ends that set of children and
+    a second, fresh set (the next variant) produces the result."""
+    out = _run(["--gpus", "2", "--device", "cpu", "--batch-per-gpu", "128", "--steps", "2", "--warmup", "1", "--steady", "0",
+                "--eval", "0"], env={"DTF_BENCH_INJECT_INIT_FAIL": "0:1"})
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["config"]["launch_variant"] == "gloo-cpu-second-try" and d["n_gpus"] == 2
+    assert "injected bring-up failure" in out.stderr and "trying the next one" in out.stderr
+
+
+def test_failed_bring_up_under_torchrun_is_tried_again():
+    """The same with one supervisor per rank (the driver's torchrun line): they agree on the retry through the
+    launcher's store."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), BENCH, "--gpus", "2", "--device", "cpu", "--batch-per-gpu", "128", "--steps", "2",
+           "--warmup", "1", "--steady", "0", "--eval", "0"]
+    out = subprocess.run(cmd, env=_env({"DTF_BENCH_INJECT_INIT_FAIL": "0:1"}), capture_output=True, text=True, timeout=300,
+                         cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    assert json.loads(lines[0])["config"]["launch_variant"] == "gloo-cpu-second-try"
+
+
+def test_every_variant_failing_is_an_error():
+    out = _run(["--gpus", "2", "--device", "cpu", "--batch-per-gpu", "128", "--steps", "2", "--warmup", "1", "--steady", "0",
+                "--eval", "0"], env={"DTF_BENCH_INJECT_INIT_FAIL": "0:1,1:0"})
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert "no launch variant" in out.stderr

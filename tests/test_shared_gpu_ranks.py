@@ -101,7 +101,8 @@ def test_bench_self_launch_two_ranks_share_the_gpu():
     assert len(lines) == 1
     d = json.loads(lines[0])
     c = d["config"]
-    assert d["n_gpus"] == 2 and c["parallelism"] == "dp2" and c["rccl_ranks"] == 2 and c["self_launched"]
+    assert d["n_gpus"] == 2 and c["parallelism"] == "dp2" and c["group_ranks"] == 2 and c["self_launched"]
+    assert c["rccl_ranks"] is None and c["backend"] == "gloo" and c["launch_variant"] == "forced-gloo"
     assert sorted(r["rank"] for r in c["ranks"]) == [0, 1] and len({r["pid"] for r in c["ranks"]}) == 2
     assert c["test_acc"] is not None and c["test_acc"] > 0.5
 
