@@ -607,6 +607,15 @@ def run_rank(args) -> None:
         if len(distinct) != world:
             raise SystemExit("bench.py: %d ranks but only %d distinct GPUs: %r" % (world, len(distinct), ranks))
 
+    # device memory this rank holds: PyTorch's allocator (variables, gradients, activations, slots) plus the
+    # peer-mapped region of the asynchronous mode, which is allocated outside it
+    hbm = None
+    if on_gpu:
+        hbm = int(torch.cuda.max_memory_allocated(dev))
+        if args.mode == "async" and getattr(strategy, "region_floats", None):
+            hbm += 4 * int(strategy.region_floats)
+    hbm_detail = strategy.hbm_report(model) if hasattr(strategy, "hbm_report") else None
+
     global_batch = B * world
     value = global_batch * args.steps / elapsed
     if rank == 0:
@@ -631,7 +640,9 @@ def run_rank(args) -> None:
                        "train_loss": logs.get("loss"), "train_acc": logs.get("acc"), "test_acc": test_acc,
                        "eval_steps": n_eval if test_acc is not None else 0,
                        "steady_warmup_steps": steady_windows * 10,
-                       "data_plane": ("peer regions (%s), control plane over TCP" % ("hipIpc over xGMI" if on_gpu else "shared memory")
+                       "hbm_bytes_per_rank": hbm, "hbm_detail": hbm_detail,
+                       "data_plane": ("peer regions (%s) + doorbell words; no control-plane call inside a step"
+                                      % ("hipIpc over xGMI" if on_gpu else "shared memory")
                                       if args.mode == "async" else {"nccl": "rccl"}.get(data_plane, data_plane)),
                        # the size of the RCCL communicator; null whenever the collectives did not go over RCCL
                        "rccl_ranks": group_size if data_plane == "nccl" else None,
@@ -640,7 +651,9 @@ def run_rank(args) -> None:
                        "self_launched": os.environ.get("DTF_BENCH_SELF_LAUNCHED") == "1",
                        "ranks": ranks,
                        **({"device": "cpu (plumbing rehearsal, not a benchmark)"} if not on_gpu else {}),
-                       **({"max_staleness": args.max_staleness, "staleness_histogram_rank0": staleness}
+                       **({"max_staleness": args.max_staleness, "staleness_histogram_rank0": staleness,
+                           "inbox_depth": strategy.depth, "wait_seconds_rank0": strategy.wait_seconds,
+                           "host_comm_seconds_rank0": strategy.comm_seconds}
                           if staleness is not None else {})},
         }
         print(json.dumps(out), flush=True)

@@ -195,7 +195,8 @@ class Sequential:
                 head.emit_logits = True
             if self.loss.fuse_with_head(head):
                 head.grad_is_dz = True
-        self.optimizer.create_slots(self.store)
+        if not getattr(self.strategy, "owns_optimizer_state", False):
+            self.optimizer.create_slots(self.store)      # (parameter-server workers hold none: their owners do)
         self.strategy.prepare(self)
         # Keras rule: 'accuracy' with a non-crossentropy loss and output dim > 1 is categorical accuracy.
         self._extra_categorical = any(m in ("accuracy", "acc", "categorical_accuracy") for m in self.metrics) \

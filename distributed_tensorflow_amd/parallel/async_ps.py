@@ -15,20 +15,24 @@ Re-designed for one MI355X node:
   itself is atomic;
 * **colocated owners** (no ps tasks, or ps tasks without a GPU of their own): a service thread
   inside every worker process owns 1/N of the flat buffer, so 8 workers on 8 GPUs shard the
-  variables across all eight HBMs.  The data plane is one-sided: a worker *puts* its gradient
-  shard into the owner's inbox slot and the owner puts fresh parameters into the worker's landing
-  zone through peer-mapped memory over xGMI (``peer_region.PeerRegion``: hipIpc on GPUs, POSIX
-  shared memory on CPUs).  No rendezvous between the two processes is needed, so owners can serve
-  workers in arrival order; two threads of a process sharing send/recv communicators cannot (their
-  blocking operations serialise on the communicator's stream and dead-lock across ranks);
+  variables across all eight HBMs and nobody else holds optimizer state.  The data plane is one-sided and stays
+  on the devices: a worker *puts* its gradient shard into the owner's inbox slot through peer-mapped memory over
+  xGMI (``peer_region.PeerRegion``: hipIpc on GPUs, POSIX shared memory on CPUs) and rings a doorbell word from a
+  host function queued behind the copies; the owner's native service thread (``csrc/kernels/owner_pump.hip``)
+  launches the fused apply kernel on its own stream and acknowledges through the same words
+  (``parallel/doorbell.py``); a worker *gets* the owners' variable shards straight into its flat buffer at the
+  start of a step.  A step makes no control-plane round trip and never waits for a stream on the host; with
+  two inbox slots per worker the next forward pass starts while the owners are still applying (that lag is
+  part of the staleness bound).  Version, staleness, ``global_step`` and the workers' clocks ride in the words;
 * **ps tasks as owners** (separate processes, as in the reference; whole variables placed
   round-robin or byte-balanced): one packed gradient message to and one packed parameter message
   from every owner per step over ``torch.distributed`` send/recv - RCCL between GPUs, gloo between
   CPU processes - instead of TF's one RecvTensor RPC per variable per direction.  Each process
   has exactly one thread on the data plane;
-* control traffic is folded: per step a worker makes one round trip per control server to queue its
-  requests, one to collect the replies (which carry the owner's version, the observed staleness
-  and the new ``global_step``), and - with a staleness bound - one to publish its clock and wait;
+* with ps tasks as owners control traffic is folded: per step a worker makes one round trip per control server to
+  queue its requests, one to collect the replies (which carry the owner's version, the observed staleness and
+  the new ``global_step``), and - with a staleness bound - one to publish its clock and wait.  The control plane
+  otherwise serves rendezvous, barriers, heartbeats, checkpoints and shutdown;
 * *bounded staleness* (stale-synchronous parallel): a worker that has completed ``c`` pushes may
   start its next step only while ``c - min(all clocks) <= max_staleness``.  ``max_staleness=None``
   is the reference's unbounded behaviour.  The observed staleness of every push (owner version at
@@ -224,12 +228,15 @@ class ParameterServerService:
     """Owner of a set of flat ranges: serves init / pushpull / pull / save / restore / stats / shutdown.
 
     Two data planes: ``region`` (a :class:`~.peer_region.PeerRegion` shared with the workers: colocated owners) or
-    ``p2p`` (``torch.distributed`` send/recv: ps tasks).  Layout of a region, in floats, with ``F`` the flat length
-    and ``S`` the shard length ``F / owners``:
+    ``p2p`` (``torch.distributed`` send/recv: ps tasks).  Layout of a region, in floats, with ``S`` the shard length
+    ``flat_len / owners``, ``W`` workers and ``D`` inbox slots per worker:
 
-    * ``[w*S, (w+1)*S)``          inbox slot of worker ``w`` (its gradient - or initial values - for this owner);
-    * ``[F + b, F + e)``          landing zone: parameters of the owner whose flat range is ``[b, e)``;
-    * ``[2F + o, ...)``           checkpoint staging: pieces of variables this rank writes, at their flat offset ``o``.
+    * ``[0, S)``                       this owner's variables (workers read them with one-sided gets);
+    * ``[S, 2S)`` and ``[2S, 3S)``     its optimizer slots (Adam m and v / momentum): nobody else holds any;
+    * ``[3S + (w*D + d)*S, ...)``      inbox slot ``d`` of worker ``w`` (its gradient shard number ``t`` with ``t % D == d``).
+
+    With a region the hot path (apply on arrival, acknowledge) is the native pump of ``doorbell.OwnerPump``; this
+    class then only serves the rare requests that arrive over the control plane (init, save, restore, stats, shutdown).
     """
 
     def __init__(self, server=None, owner_index: Optional[int] = None, control: Optional[ControlClient] = None,
@@ -265,6 +272,9 @@ class ParameterServerService:
         self._owns_group = False
         self.stream = None
         self.error: Optional[BaseException] = None
+        self.blocks = None                  # doorbell.ControlBlocks (region mode)
+        self.depth = 1
+        self.pump = None
 
     # a tiny VariableStore look-alike so Optimizer.apply works on the owned shard
     class _Shard:
@@ -279,7 +289,14 @@ class ParameterServerService:
         def slot(self, name):
             s = self._svc.slots
             if name not in s:
-                s[name] = torch.zeros_like(self._svc.var)
+                svc = self._svc
+                if svc.region is not None:
+                    # slots live in the region, behind the variables: m / momentum first, v second
+                    k = 2 if name == "v" else 1
+                    s[name] = svc.region.local[k * svc.slot_len:k * svc.slot_len + max(svc.n, 1)]
+                    s[name].zero_()
+                else:
+                    s[name] = torch.zeros_like(svc.var)
             return s[name]
 
     def _join_data_plane(self):
@@ -299,9 +316,14 @@ class ParameterServerService:
         self.ranges = self.all_ranges[self.owner_index]
         self.variables = [(n, int(o), int(k), tuple(s)) for n, o, k, s in layout["variables"]]
         self.flat_len = int(layout["flat_len"])
-        n = _ranges_numel(self.ranges)
-        self.var = torch.zeros(max(n, 1), dtype=torch.float32, device=self.device)
-        self.grad = torch.zeros_like(self.var) if self.region is None else None
+        n = self.n = _ranges_numel(self.ranges)
+        if self.region is not None:
+            self.slot_len = self.flat_len // self.num_owners
+            self.var = self.region.local[0:max(n, 1)]
+            self.grad = None
+        else:
+            self.var = torch.zeros(max(n, 1), dtype=torch.float32, device=self.device)
+            self.grad = torch.zeros_like(self.var)
         self.step_t = torch.zeros(1, dtype=torch.int64, device=self.device)
         o = layout["optimizer"]
         self.opt = optimizers.Adam(**o["args"]) if o["name"] == "Adam" else optimizers.SGD(**o["args"])
@@ -310,26 +332,35 @@ class ParameterServerService:
         self.opt.create_slots(self.shard)
         self.n = n
         self.pieces = owned_pieces(self.variables, self.ranges)
-        if self.region is not None:
-            self.slot_len = self.flat_len // self.num_owners
 
-    # -- transport
+    # -- the native hot path of a region owner
+    def _start_pump(self):
+        from .doorbell import OwnerPump
+        S = self.slot_len
+        self.pump = OwnerPump(device=self.device, owner=self.owner_index, workers=self.num_workers, depth=self.depth,
+                              n=self.n, slot_stride=S, var=self.var, m=self.slots.get("m", self.slots.get("momentum")),
+                              v=self.slots.get("v"), inbox=self.region.local[3 * S:], step=self.step_t,
+                              beta_powers=self.beta_powers, optimizer=self.opt,
+                              ctl_address=self.blocks.block_address(self.owner_index))
+
+    def _quiesce(self):
+        """Stop applying (what is launched completes): the shard is stable until ``_release``."""
+        if self.pump is not None:
+            self.pump.pause()
+
+    def _release(self, resync: bool = False):
+        if self.pump is not None:
+            self.pump.resume(resync)
+
+    # -- transport (ps tasks)
     def _incoming(self, worker: int, wr, tag: int) -> torch.Tensor:
         """The tensor worker ``worker`` sent for this request (gradient, or initial values)."""
-        if self.region is not None:
-            b = worker * self.slot_len
-            return self.region.local[b:b + self.n]        # written and synchronised before the request was queued
         buf = self.grad if tag == _TAG_PUSH else self.var
         self.p2p.recv(buf[:self.n], wr, tag)
         return buf[:self.n]
 
     def _send_params(self, worker: int, wr):
-        if self.region is not None:
-            b = self.flat_len + self.ranges[0][0]
-            self.region.put(worker, b, self.var[:self.n])
-            self.region.sync()                             # complete and visible before the reply is published
-        else:
-            self.p2p.send(self.var[:self.n], wr, _TAG_PULL)
+        self.p2p.send(self.var[:self.n], wr, _TAG_PULL)
 
     def _reply(self, worker: int, staleness: int, count_step: bool, seq: int = 0):
         # `seq` echoes the request's sequence number: a worker that gave up on a slow reply (ControlTimeout, then
@@ -367,7 +398,9 @@ class ParameterServerService:
                         return
         if self.device.type == "cuda":
             torch.cuda.set_device(self.device)
-            self.stream = torch.cuda.Stream(device=self.device)     # applies overlap the worker's compute stream
+            # ps tasks apply on this stream; a region owner's pump has a stream of its own and this one only carries
+            # the rare requests (initialisation, checkpoints)
+            self.stream = torch.cuda.Stream(device=self.device)
         if self.region is None and self.p2p is None:
             self._join_data_plane()      # only clusters that use their ps tasks put them on the data plane
             self.p2p = _P2P(self.rank)
@@ -376,7 +409,12 @@ class ParameterServerService:
         with ctx:
             self._configure(layout)
             self.cp0.add(self.ns + "/ready", 1)
-            self._loop()
+            try:
+                self._loop()
+            finally:
+                if self.pump is not None:
+                    pump, self.pump = self.pump, None
+                    pump.stop()
         self.cp0.add(self.ns + "/stopped", 1)
         if self._owns_group and dist.is_initialized():
             try:
@@ -389,6 +427,8 @@ class ParameterServerService:
             try:
                 req = self.cp.pop_json(self.queue, timeout_s=5.0)
             except ControlTimeout:
+                if self.pump is not None and self.pump.error():
+                    raise RuntimeError("the owner pump failed with status %d" % self.pump.error())
                 continue
             op = req["op"]
             if op == "shutdown":
@@ -397,10 +437,12 @@ class ParameterServerService:
             wr = self.worker_rank_of(w) if w is not None else None
             seq = int(req.get("seq", 0))
             if op == "init":
-                if self.n:
+                self._quiesce()
+                if self.n and self.region is None:
                     src = self._incoming(w, wr, _TAG_INIT)
                     if src.data_ptr() != self.var.data_ptr():
                         self.var[:self.n].copy_(src)
+                # (a region owner's variables were put into place by the chief before it queued this request)
                 for s in self.slots.values():
                     s.zero_()
                 self.version = 0
@@ -409,6 +451,12 @@ class ParameterServerService:
                 self.beta_powers.copy_(optimizers.initial_beta_powers(self.opt, self.device))
                 if self.stream is not None:
                     self.stream.synchronize()
+                if self.region is not None:
+                    self.blocks.rebase_step(self.owner_index, int(req.get("global_step", 0)))
+                    if self.pump is None:
+                        self._start_pump()
+                    else:
+                        self._release()
                 self.cp0.add(self.ns + "/init_done", 1)
             elif op == "pushpull":
                 if self.n:
@@ -418,97 +466,113 @@ class ParameterServerService:
                 st = self.version - int(req.get("version", self.version))
                 self.staleness_hist[st] = self.staleness_hist.get(st, 0) + 1
                 self.version += 1
-                if self.region is not None:
-                    if self.n:
-                        self._send_params(w, wr)
-                    self._reply(w, st, self.owner_index == 0, seq)
-                else:
-                    # the reply first: the worker reads it after its receive has completed anyway, and a send
-                    # that waits for the peer must not delay it
-                    self._reply(w, st, self.owner_index == 0, seq)
-                    if self.n:
-                        self._send_params(w, wr)
+                # the reply first: the worker reads it after its receive has completed anyway, and a send
+                # that waits for the peer must not delay it
+                self._reply(w, st, self.owner_index == 0, seq)
+                if self.n:
+                    self._send_params(w, wr)
             elif op == "pull":
-                if self.region is not None:
-                    if self.n:
-                        self._send_params(w, wr)
-                    self._reply(w, 0, False, seq)
-                else:
-                    self._reply(w, 0, False, seq)
-                    if self.n:
-                        self._send_params(w, wr)
+                self._reply(w, 0, False, seq)
+                if self.n:
+                    self._send_params(w, wr)
             elif op == "save":
                 self._save(req)
             elif op == "restore":
                 self._restore(req)
             elif op == "stats":
+                if self.region is not None:
+                    version = self.blocks.version(self.owner_index)
+                    hist = self.pump.histogram() if self.pump is not None else {}
+                else:
+                    version, hist = self.version, self.staleness_hist
                 self.cp.set_json("%s/stats/%d" % (self.ns, self.owner_index),
-                                 {"version": self.version, "staleness": {str(k): v for k, v in self.staleness_hist.items()}})
+                                 {"version": version, "staleness": {str(k): v for k, v in hist.items()}})
+            if self.pump is not None and self.pump.error():
+                raise RuntimeError("the owner pump failed with status %d" % self.pump.error())
 
     # -- checkpoints
     def _save(self, req):
         """This owner's part of a checkpoint: data shard ``owner_index`` with the variables this owner *writes* - those
         whose first element it owns - and their optimizer slots.  A variable that straddles owners (flat sharding)
-        is first assembled in the writer's staging area: every owner puts the pieces it holds there."""
+        is assembled by its writer with one-sided gets from the regions of the owners that hold the rest; every owner
+        has stopped applying while that goes on."""
         from ..saver import BundleWriter
         token = req["token"]
         gather = bool(req.get("gather"))
         if gather and self.region is None:
             raise RuntimeError("variables split across ps tasks cannot be checkpointed by their owners")
         kinds = [("", None)] + [(suffix, slot) for slot, suffix in sorted(req["slots"].items()) if slot in self.slots]
-        stage = 2 * self.flat_len
         w = BundleWriter(req["prefix"], req["num_shards"], only_shard=self.owner_index)
+        self._quiesce()
         try:
+            if gather:
+                self.cp0.barrier("%s/ckpt/%s/in" % (self.ns, token), self.num_owners, timeout_s=600)
             for suffix, slot in kinds:
                 src = self.var if slot is None else self.slots[slot]
-                if gather:
-                    for p in self.pieces:
-                        if p["n"] != p["numel"]:
-                            writer = owner_of_element(self.all_ranges, p["offset"])
-                            self.region.put(writer, stage + p["offset"] + p["lo"], src[p["shard_off"]:p["shard_off"] + p["n"]])
-                    self.region.sync()
-                    self.cp0.barrier("%s/ckpt/%s/%s/in" % (self.ns, token, suffix), self.num_owners, timeout_s=600)
+                plane = 0 if slot is None else (2 if slot == "v" else 1)      # which third of a region holds it
                 for p in self.pieces:
                     if p["lo"] != 0:
                         continue                                   # written by the owner of the variable's first element
                     if p["n"] == p["numel"]:
                         t = src[p["shard_off"]:p["shard_off"] + p["numel"]]
                     else:
-                        t = self.region.local[stage + p["offset"]:stage + p["offset"] + p["numel"]]
+                        t = torch.empty(p["numel"], dtype=torch.float32, device=self.device)
+                        t[:p["n"]].copy_(src[p["shard_off"]:p["shard_off"] + p["n"]])
+                        S = self.slot_len
+                        pos = p["offset"] + p["n"]                 # flat index of the first element somebody else holds
+                        while pos < p["offset"] + p["numel"]:
+                            j = pos // S
+                            n = min(p["offset"] + p["numel"], (j + 1) * S) - pos
+                            self.region.get(j, plane * S + (pos - j * S), t[pos - p["offset"]:pos - p["offset"] + n])
+                            pos += n
+                        self.region.sync()
                     name = p["name"] if not suffix else "%s/%s" % (p["name"], suffix)
                     w.add(name, t.reshape(p["shape"]), self.owner_index)
-                if gather:
-                    self.cp0.barrier("%s/ckpt/%s/%s/out" % (self.ns, token, suffix), self.num_owners, timeout_s=600)
             if self.owner_index == 0:
                 w.add("global_step", torch.tensor(int(req["global_step"]), dtype=torch.int64), 0)
                 if req["optimizer"] == "Adam":
                     w.add("beta1_power", self.beta_powers[0], 0)
                     w.add("beta2_power", self.beta_powers[1], 0)
             w.finish()
+            if gather:
+                self.cp0.barrier("%s/ckpt/%s/out" % (self.ns, token), self.num_owners, timeout_s=600)
         except Exception:
             w.abort()
             raise
+        finally:
+            self._release()
         self.cp0.add("%s/save_done/%s" % (self.ns, token), 1)
 
     def _restore(self, req):
         """Reload this owner's pieces - variables, optimizer slots, ``beta*_power``, the step - from a checkpoint."""
         from ..saver import BundleReader
-        with BundleReader(req["prefix"]) as r:
-            for p in self.pieces:
-                sl = slice(p["shard_off"], p["shard_off"] + p["n"])
-                self.var[sl].copy_(r.get_tensor(p["name"]).reshape(-1)[p["lo"]:p["lo"] + p["n"]])
-                for slot, suffix in req["slots"].items():
-                    key = "%s/%s" % (p["name"], suffix)
-                    if r.has_tensor(key):
-                        self.shard.slot(slot)[sl].copy_(r.get_tensor(key).reshape(-1)[p["lo"]:p["lo"] + p["n"]])
-            if r.has_tensor("global_step"):
-                self.step_t.fill_(int(r.get_tensor("global_step").item()))
-            if r.has_tensor("beta1_power"):
-                self.beta_powers[0] = r.get_tensor("beta1_power")
-                self.beta_powers[1] = r.get_tensor("beta2_power")
-        self.version = 0
-        if self.stream is not None:
-            self.stream.synchronize()
+        self._quiesce()
+        try:
+            with BundleReader(req["prefix"]) as r:
+                for p in self.pieces:
+                    sl = slice(p["shard_off"], p["shard_off"] + p["n"])
+                    self.var[sl].copy_(r.get_tensor(p["name"]).reshape(-1)[p["lo"]:p["lo"] + p["n"]])
+                    for slot, suffix in req["slots"].items():
+                        key = "%s/%s" % (p["name"], suffix)
+                        if r.has_tensor(key):
+                            self.shard.slot(slot)[sl].copy_(r.get_tensor(key).reshape(-1)[p["lo"]:p["lo"] + p["n"]])
+                gs = None
+                if r.has_tensor("global_step"):
+                    gs = int(r.get_tensor("global_step").item())
+                    self.step_t.fill_(gs)
+                if r.has_tensor("beta1_power"):
+                    self.beta_powers[0] = r.get_tensor("beta1_power")
+                    self.beta_powers[1] = r.get_tensor("beta2_power")
+            self.version = 0
+            if self.stream is not None:
+                self.stream.synchronize()
+            if self.region is not None:
+                if gs is not None:
+                    self.blocks.rebase_step(self.owner_index, gs)
+                if self.pump is None:
+                    self._start_pump()
+        finally:
+            self._release()
         self.cp0.add("%s/restore_done/%s" % (self.ns, req["token"]), 1)
 
 
@@ -563,6 +627,16 @@ class AsyncPSStrategy:
         self._staging: Dict = {}
         self.region = None
         self.p2p = None
+        self.blocks = None            # doorbell.ControlBlocks: the owners' words (colocated owners)
+        self.depth = 1                # inbox slots per (owner, worker): gradients a worker may have outstanding
+        self._pulled: List[int] = []  # owner versions seen at the last pull
+        self._sent_pulled: List[List[int]] = []   # [slot][owner]: the same, as sent along with the gradient in that slot
+        self._acked: List[int] = []   # acknowledgements of each owner already accounted for in the histogram
+        self._comm_stream = None
+        self._ev_grad = self._ev_copied = None
+
+    #: nobody but the owners holds optimizer state: ``compile`` must not allocate slot buffers on a worker
+    owns_optimizer_state = True
 
     def var_alignment(self) -> int:
         return 64 * max(1, self.num_owners)
@@ -665,17 +739,34 @@ class AsyncPSStrategy:
         self.gather = any(p["n"] != p["numel"] for j in range(self.num_owners)
                           for p in owned_pieces(self.var_table, self.ranges[j]))
         if self.colocated:
-            # one-sided data plane: inbox slots + landing zone + checkpoint staging, three flat images per rank
+            # one-sided data plane.  A rank's region: its variable shard, its two optimizer-slot shards, and
+            # `depth` inbox slots per worker.  Two slots let a worker compute its next step while the owners still
+            # apply the last one; a worker that may not run ahead at all (max_staleness 0) needs one, and so does a
+            # model whose second set of slots would cost more than a gigabyte per rank.
+            from .doorbell import ControlBlocks
             from .peer_region import PeerRegion
-            self.slot_len = store.flat_len // self.num_owners
-            self.region = PeerRegion(self.worker_index, self.num_workers, 3 * store.flat_len, dev, self.cp0,
+            import os
+            S = self.slot_len = store.flat_len // self.num_owners
+            depth = 1 if (self.max_staleness == 0 or store.flat_len * 4 > (1 << 30)) else 2
+            self.depth = max(1, min(4, int(os.environ.get("DTF_ASYNC_INBOX_DEPTH", depth))))
+            self.region_floats = 3 * S + self.num_workers * self.depth * S
+            self.region = PeerRegion(self.worker_index, self.num_workers, self.region_floats, dev, self.cp0,
                                      name="co/region", timeout_s=self.timeout_s)
+            self.blocks = ControlBlocks(self.worker_index, self.num_workers, self.cp0, name="co/ctl",
+                                        timeout_s=self.timeout_s)
+            self._pulled = [0] * self.num_owners
+            self._sent_pulled = [[0] * self.num_owners for _ in range(self.depth)]
+            self._acked = [0] * self.num_owners
+            if dev.type == "cuda":
+                self._comm_stream = torch.cuda.Stream(device=dev)
+                self._ev_grad, self._ev_copied = torch.cuda.Event(), torch.cuda.Event()
             svc = ParameterServerService(server=srv, owner_index=self.worker_index,
                                          control=ControlClient(*srv.control_address(0), timeout_s=self.timeout_s),
                                          control0=ControlClient(*srv.control_address(0), timeout_s=self.timeout_s),
                                          rank=self.my_rank, device=dev, region=self.region,
                                          num_workers=self.num_workers, worker_rank_of=lambda i: i,
                                          num_owners=self.num_owners, ns=self.ns)
+            svc.blocks, svc.depth = self.blocks, self.depth
             self._service = svc
             self._service_thread = threading.Thread(target=self._run_service, name="dtf-owner-%d" % self.worker_index,
                                                     daemon=True)
@@ -707,7 +798,7 @@ class AsyncPSStrategy:
         else:
             self.cp0.get(self.ns + "/initialized", timeout_s=self.timeout_s)
         self.pull(model)
-        if self.max_staleness is not None:
+        if self.max_staleness is not None and self.region is None:
             self.cp0.clock_set_wait("workers", self.worker_index, 0, None)
 
     def close(self, grace_s: float = 20.0):
@@ -725,12 +816,17 @@ class AsyncPSStrategy:
         if self.region is not None and (t is None or not t.is_alive()):
             self.region.close()
             self.region = None
+            if self.blocks is not None:
+                self.blocks.close()
+                self.blocks = None
 
     def _run_service(self):
         try:
             self._service.serve()
         except BaseException:       # noqa: BLE001 - kept in service.error; the training thread raises it
-            pass
+            import sys
+            import traceback
+            sys.stderr.write("owner service of worker %d failed:\n%s" % (self.worker_index, traceback.format_exc()))
 
     def _stage(self, j: int, store, kind: str = "p") -> torch.Tensor:
         key = (j, kind)
@@ -745,7 +841,7 @@ class AsyncPSStrategy:
         if self.region is not None:
             for j in range(self.num_owners):
                 b, e = self.ranges[j][0]
-                self.region.put(j, self.worker_index * self.slot_len, store.flat[b:e])
+                self.region.put(j, 0, store.flat[b:e])       # straight into the owner's variable shard
             self.region.sync()
             self._post("init", {"global_step": gs0})
         else:
@@ -758,17 +854,110 @@ class AsyncPSStrategy:
                                   self.owner_rank(j), _TAG_INIT))
             self.p2p.exchange(sends, [])
         self._wait_counter(self.ns + "/init_done", base + self.num_owners)
-        self.cp0.add("global_step", gs0 - self.cp0.add("global_step", 0))
+        if self.region is None:
+            self.cp0.add("global_step", gs0 - self.cp0.add("global_step", 0))
         self.last_global_step = gs0
 
-    # -- data movement
+    # -- data movement: colocated owners (peer regions + doorbell words; nothing here crosses a socket)
+    def _health(self):
+        self._check_service()
+        svc = self._service
+        if svc is not None and svc.pump is not None and svc.pump.error():
+            raise RuntimeError("the owner pump of this worker failed with status %d" % svc.pump.error())
+
+    def _spin(self, pred, what: str) -> float:
+        from .doorbell import spin_until
+        try:
+            return spin_until(pred, self.timeout_s, what, check=self._health)
+        except TimeoutError as e:
+            raise ControlTimeout(str(e)) from e
+
+    def _min_ack(self) -> int:
+        b, w = self.blocks, self.worker_index
+        return min(b.ack(j, w) for j in range(self.num_owners))
+
+    def _account_acks(self):
+        """Histogram the staleness of every push acknowledged since the last call: owner updates applied between the
+        pull a gradient was computed from and its own apply.  Must run before a slot's words are reused."""
+        b, w, D = self.blocks, self.worker_index, self.depth
+        for j in range(self.num_owners):
+            upto = b.ack(j, w)
+            for seq in range(self._acked[j] + 1, upto + 1):
+                slot = (seq - 1) % D
+                st = max(0, b.ack_version(j, w, slot) - 1 - self._sent_pulled[slot][j])
+                self.staleness_hist[st] = self.staleness_hist.get(st, 0) + 1
+            self._acked[j] = upto
+
+    def _drain(self):
+        """Wait until the owners have applied everything this worker has pushed."""
+        if self.clock:
+            self._spin(lambda: self._min_ack() >= self.clock, "the owners to apply this worker's gradients")
+        self._account_acks()
+
+    def _region_pull(self, store):
+        """One-sided gets of every owner's variable shard straight into the flat buffer, on the current stream."""
+        for j in range(self.num_owners):
+            self._pulled[j] = self.blocks.version(j)
+            b, e = self.ranges[j][0]
+            self.region.get(j, 0, store.flat[b:e])
+        self.versions = list(self._pulled)
+        self.last_global_step = self.blocks.global_step()
+
+    def _region_step(self, model):
+        """Push this step's gradient shards, then fetch the variables for the next step."""
+        store = model.store
+        on_gpu = store.device.type == "cuda"
+        W, D, w = self.num_owners, self.depth, self.worker_index
+        t = self.clock                                   # gradients pushed so far; this one is number t + 1
+        slot = t % D
+        # the inbox slot is free once the gradient that used it last (number t + 1 - D) has been applied
+        if t >= D:
+            self.wait_seconds += self._spin(lambda: self._min_ack() >= t + 1 - D, "a free inbox slot")
+        self._account_acks()
+        if on_gpu:
+            cur = torch.cuda.current_stream(store.device)
+            self._ev_grad.record(cur)
+            self._comm_stream.wait_event(self._ev_grad)
+            ctx = torch.cuda.stream(self._comm_stream)
+        else:
+            ctx = _NullContext()
+        with ctx:
+            base = 3 * self.slot_len + (w * D + slot) * self.slot_len
+            for j in range(W):
+                b, e = self.ranges[j][0]
+                self.region.put(j, base, store.flat_grad[b:e])
+            if on_gpu:
+                self._ev_copied.record(self._comm_stream)
+            from .doorbell import ring
+            self._sent_pulled[slot] = list(self._pulled)
+            ring(self._comm_stream.cuda_stream if on_gpu else 0, on_gpu,
+                 [self.blocks.lane_address(j, w) for j in range(W)], self._pulled, slot, t + 1, t + 1)
+        if on_gpu:
+            cur.wait_event(self._ev_copied)              # the next backward pass may overwrite the gradient buffer
+        self.clock = t + 1
+        # how far this worker may run ahead of the owners: one gradient in flight per spare inbox slot
+        lag = D - 1
+        if self._min_ack() < self.clock - lag:
+            self.wait_seconds += self._spin(lambda: self._min_ack() >= self.clock - lag, "the owners' acknowledgement")
+        if self.max_staleness is not None:
+            # stale-synchronous bound over the workers' clocks (completed pushes), read from owner 0's block
+            s = self.max_staleness
+            if self.clock - self.blocks.min_clock() > s:
+                self.wait_seconds += self._spin(lambda: self.clock - self.blocks.min_clock() <= s,
+                                                "the slowest worker (staleness bound)")
+        self._region_pull(store)
+        if self.last_global_step:
+            store.global_step.fill_(self.last_global_step)
+
+    def min_clock(self) -> int:
+        """The slowest worker's clock (pushes completed), as the staleness bound sees it."""
+        if self.blocks is not None:
+            return self.blocks.min_clock()
+        return self.cp0.clock_min("workers")
+
+    # -- data movement: ps tasks (torch.distributed send/recv + folded control traffic)
     def _receive_params(self, store):
-        """Parameters of every owner into ``store.flat`` (after the owners have been asked)."""
-        if self.region is not None:
-            reps = self._collect()           # owners reply after their put has completed
-            F = self.flat_len
-            store.flat.copy_(self.region.local[F:2 * F])
-            return reps
+        """Receive descriptors for the parameters of every owner (after the owners have been asked)."""
         recvs, bufs = [], {}
         for j in range(self.num_owners):
             n = _ranges_numel(self.ranges[j])
@@ -781,16 +970,18 @@ class AsyncPSStrategy:
         return recvs, bufs
 
     def pull(self, model):
+        """The owners' current variables into this worker's flat buffer (everything it pushed has been applied)."""
         store = model.store
-        self._post("pull")
         if self.region is not None:
-            reps = self._receive_params(store)
-        else:
-            recvs, bufs = self._receive_params(store)
-            self.p2p.exchange([], recvs)
-            for j, buf in bufs.items():
-                _unpack(buf, store.flat, self.ranges[j])
-            reps = self._collect()
+            self._drain()
+            self._region_pull(store)
+            return
+        self._post("pull")
+        recvs, bufs = self._receive_params(store)
+        self.p2p.exchange([], recvs)
+        for j, buf in bufs.items():
+            _unpack(buf, store.flat, self.ranges[j])
+        reps = self._collect()
         for j, rep in enumerate(reps):
             self.versions[j] = rep["version"]
 
@@ -799,27 +990,24 @@ class AsyncPSStrategy:
         store = model.store
         t_begin = time.perf_counter()
         if self.region is not None:
-            for j in range(self.num_owners):
-                b, e = self.ranges[j][0]
-                self.region.put(j, self.worker_index * self.slot_len, store.flat_grad[b:e])
-            self.region.sync()                # gradients computed, copied and visible before the owners hear of them
-            self._post("pushpull", lambda j: {"version": self.versions[j]})
-            reps = self._receive_params(store)
-        else:
-            self._post("pushpull", lambda j: {"version": self.versions[j]})
-            sends = []
-            for j in range(self.num_owners):
-                n = _ranges_numel(self.ranges[j])
-                if not n:
-                    continue
-                g = store.flat_grad[self.ranges[j][0][0]:self.ranges[j][0][1]] if len(self.ranges[j]) == 1 \
-                    else _pack(store.flat_grad, self.ranges[j], self._stage(j, store, "g"))[:n]
-                sends.append((g, self.owner_rank(j), _TAG_PUSH))
-            recvs, bufs = self._receive_params(store)
-            self.p2p.exchange(sends, recvs)
-            for j, buf in bufs.items():
-                _unpack(buf, store.flat, self.ranges[j])
-            reps = self._collect()
+            w0 = self.wait_seconds
+            self._region_step(model)
+            self.comm_seconds += time.perf_counter() - t_begin - (self.wait_seconds - w0)
+            return
+        self._post("pushpull", lambda j: {"version": self.versions[j]})
+        sends = []
+        for j in range(self.num_owners):
+            n = _ranges_numel(self.ranges[j])
+            if not n:
+                continue
+            g = store.flat_grad[self.ranges[j][0][0]:self.ranges[j][0][1]] if len(self.ranges[j]) == 1 \
+                else _pack(store.flat_grad, self.ranges[j], self._stage(j, store, "g"))[:n]
+            sends.append((g, self.owner_rank(j), _TAG_PUSH))
+        recvs, bufs = self._receive_params(store)
+        self.p2p.exchange(sends, recvs)
+        for j, buf in bufs.items():
+            _unpack(buf, store.flat, self.ranges[j])
+        reps = self._collect()
         for j, rep in enumerate(reps):
             self.versions[j] = rep["version"]
             self.staleness_hist[rep["staleness"]] = self.staleness_hist.get(rep["staleness"], 0) + 1
@@ -836,14 +1024,32 @@ class AsyncPSStrategy:
             self.wait_seconds += time.perf_counter() - t_comm
 
     def global_step(self) -> int:
-        """Cluster-wide global step (one control-plane round trip)."""
+        """Cluster-wide global step.  Colocated owners: the word owner 0 publishes, after this worker's own pushes
+        have been applied (no round trip); ps tasks: one control-plane round trip."""
+        if self.blocks is not None:
+            self._drain()
+            self.last_global_step = self.blocks.global_step()
+            return self.last_global_step
         self.last_global_step = self.cp0.add("global_step", 0)
         return self.last_global_step
 
     def cached_global_step(self) -> int:
-        """The shared step as of this worker's last push (it travels back with owner 0's reply): what session hooks
-        read after every ``run``, without a round trip."""
+        """The shared step without waiting for anything: what session hooks read after every ``run``.  Colocated
+        owners publish it in shared memory; with ps tasks it is the value that came back with the last push."""
+        if self.blocks is not None:
+            self.last_global_step = max(self.last_global_step, self.blocks.global_step())
         return self.last_global_step
+
+    def hbm_report(self, model) -> dict:
+        """Bytes this rank holds for the model: what a worker needs (variables + gradients) and what it owns."""
+        F = model.store.flat_len * 4
+        out = {"worker_variables": F, "worker_gradients": F,
+               "worker_slots": sum(t.numel() * 4 for t in model.store.slots.values())}
+        if self.region is not None:
+            S = self.slot_len * 4
+            out.update({"owner_variables": S, "owner_slots": 2 * S, "owner_inbox": self.num_workers * self.depth * S,
+                        "region_total": self.region_floats * 4})
+        return out
 
     def publish_state(self, model, is_chief: bool):
         """Session creation: the chief (re-)initialises the owners - from the checkpoint it has just restored, slots
@@ -858,7 +1064,8 @@ class AsyncPSStrategy:
             if prefix:
                 model._restored_from = None
                 self.restore(model, prefix, uuid.uuid4().hex)
-                self.cp0.add("global_step", gs - self.cp0.add("global_step", 0))
+                if self.region is None:
+                    self.cp0.add("global_step", gs - self.cp0.add("global_step", 0))
                 self.last_global_step = gs
             else:
                 self._init_owners(store, gs)
@@ -900,8 +1107,12 @@ class AsyncPSStrategy:
 
     def worker_done(self):
         """Every worker calls this once after its last step."""
+        if self.blocks is not None:
+            self._drain()
+            self.blocks.set_clock(self.worker_index, 1 << 60)       # a finished worker never holds others back
+        else:
+            self.cp0.clock_set("workers", self.worker_index, 1 << 60)
         self.cp0.add("workers_done", 1)
-        self.cp0.clock_set("workers", self.worker_index, 1 << 60)   # a finished worker never holds others back
 
     def shutdown_owners(self, wait_for_workers: bool = True):
         """Chief only: ends ``server.join()`` in every ps task and every colocated owner thread (the reference has

@@ -1,0 +1,238 @@
+"""Doorbell words and the native owner pump of the asynchronous parameter-server mode.
+
+Every owner has one *control block* in host memory shared by all processes of the node (POSIX shared memory): a
+header (``version``, ``global_step``) and one 128-byte *lane* per worker with the worker's doorbell / clock and the
+owner's acknowledgement.  Workers and owners exchange gradients and parameters through peer-mapped device memory
+(:mod:`.peer_region`); these words are all that tells the other side that data is complete, so a training step makes
+no control-plane round trip and never synchronises a stream on the host.  The layout is the one of
+``csrc/kernels/owner_pump.hip`` (``Ctl`` / ``Lane``), which also holds the owner's service thread.
+
+The reference's counterpart is TF's gRPC worker service inside ``server.join()``
+(/root/reference/example.py:128-131): it executes ``ApplyAdam`` for every gradient that arrives.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import time
+import uuid
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from ..ops import _native as nv
+
+MAX_DEPTH = 4
+HIST = 64
+# word indices inside a lane (uint64 units) and inside the header
+_DOOR, _CLOCK, _PULLV, _ACK, _ACKV = 0, 1, 2, 8, 9
+_LANE_WORDS = 16
+_HDR_WORDS = 16
+_VERSION, _GSTEP, _GSBASE = 0, 1, 2
+
+_lib = None
+
+
+def _k():
+    global _lib
+    if _lib is None:
+        lib = nv.kernels()
+        p, ll, ull = C.c_void_p, C.c_longlong, C.c_ulonglong
+        nv.declare(lib, "dtf_pump_config_bytes", [])
+        nv.declare(lib, "dtf_pump_lane_bytes", [])
+        nv.declare(lib, "dtf_pump_ctl_bytes", [C.c_int], ll)
+        nv.declare(lib, "dtf_pump_start", [p], p)
+        nv.declare(lib, "dtf_pump_pause", [p])
+        nv.declare(lib, "dtf_pump_resume", [p, C.c_int])
+        nv.declare(lib, "dtf_pump_error", [p])
+        nv.declare(lib, "dtf_pump_stream", [p], p)
+        nv.declare(lib, "dtf_pump_histogram", [p, p], None)
+        nv.declare(lib, "dtf_pump_stop", [p])
+        nv.declare(lib, "dtf_doorbell_ring", [p, C.c_int, p, p, C.c_int, C.c_int, ull, ull])
+        assert lib.dtf_pump_lane_bytes() == _LANE_WORDS * 8
+        _lib = lib
+    return _lib
+
+
+class _PumpConfig(C.Structure):
+    _fields_ = [("on_gpu", C.c_int), ("owner", C.c_int), ("workers", C.c_int), ("depth", C.c_int),
+                ("optimizer", C.c_int), ("pad", C.c_int),
+                ("n", C.c_longlong), ("slot_stride", C.c_longlong),
+                ("var", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("inbox", C.c_void_p),
+                ("step", C.c_void_p), ("beta_powers", C.c_void_p), ("ticket", C.c_void_p),
+                ("lr", C.c_float), ("b1", C.c_float), ("b2", C.c_float), ("eps", C.c_float), ("momentum", C.c_float),
+                ("pad2", C.c_int), ("ctl", C.c_void_p)]
+
+
+class ControlBlocks:
+    """The control blocks of all owners, mapped into this process.  Construction is collective over the ``world``
+    ranks sharing ``name`` on the control plane ``cp`` (rank ``r`` creates owner ``r``'s block)."""
+
+    def __init__(self, rank: int, world: int, cp, name: str = "co/ctl", timeout_s: float = 300.0):
+        from multiprocessing import resource_tracker, shared_memory
+        self.rank, self.world = int(rank), int(world)
+        nbytes = (_HDR_WORDS + _LANE_WORDS * self.world) * 8
+        seg = "dtfc_%s_%d" % (uuid.uuid4().hex[:12], self.rank)
+        self._mine = shared_memory.SharedMemory(name=seg, create=True, size=nbytes)
+        self._mine.buf[:nbytes] = bytes(nbytes)
+        cp.set("%s/handle/%d" % (name, self.rank), seg.encode())
+        self._shms: List = [None] * self.world
+        self._shms[self.rank] = self._mine
+        for r in range(self.world):
+            if r == self.rank:
+                continue
+            peer = cp.get("%s/handle/%d" % (name, r), timeout_s=timeout_s).decode()
+            shm = shared_memory.SharedMemory(name=peer)
+            try:        # the attaching process must not unlink the creator's segment when it exits
+                resource_tracker.unregister(shm._name, "shared_memory")
+            except Exception:
+                pass
+            self._shms[r] = shm
+        self.words = [np.frombuffer(s.buf, dtype=np.uint64, count=nbytes // 8) for s in self._shms]
+        self._base = [C.addressof(C.c_char.from_buffer(s.buf)) for s in self._shms]
+        cp.barrier("%s/mapped" % name, self.world, timeout_s=timeout_s)
+
+    # ---- addresses for the native side
+    def block_address(self, owner: int) -> int:
+        return self._base[owner]
+
+    def lane_address(self, owner: int, worker: int) -> int:
+        return self._base[owner] + (_HDR_WORDS + _LANE_WORDS * worker) * 8
+
+    # ---- words
+    def _lane(self, owner: int, worker: int) -> int:
+        return _HDR_WORDS + _LANE_WORDS * worker
+
+    def version(self, owner: int) -> int:
+        return int(self.words[owner][_VERSION])
+
+    def global_step(self) -> int:
+        return int(self.words[0][_GSTEP])
+
+    def ack(self, owner: int, worker: int) -> int:
+        return int(self.words[owner][self._lane(owner, worker) + _ACK])
+
+    def ack_version(self, owner: int, worker: int, slot: int) -> int:
+        return int(self.words[owner][self._lane(owner, worker) + _ACKV + slot])
+
+    def door(self, owner: int, worker: int) -> int:
+        return int(self.words[owner][self._lane(owner, worker) + _DOOR])
+
+    def clock(self, worker: int) -> int:
+        return int(self.words[0][self._lane(0, worker) + _CLOCK])
+
+    def set_clock(self, worker: int, value: int):
+        self.words[0][self._lane(0, worker) + _CLOCK] = np.uint64(value)
+
+    def min_clock(self) -> int:
+        w = self.words[0]
+        return int(min(int(w[self._lane(0, i) + _CLOCK]) for i in range(self.world)))
+
+    def rebase_step(self, owner: int, global_step: int):
+        """Owner (re-)initialised or restored with the cluster-wide step at ``global_step``: doors, acknowledgements
+        and ``version`` stay monotonic (workers keep counting), only the step's base moves.  Pump paused."""
+        w = self.words[owner]
+        version = int(w[_VERSION])
+        w[_GSBASE] = np.uint64((int(global_step) - version) % (1 << 64))
+        w[_GSTEP] = np.uint64(int(global_step))
+
+    def close(self):
+        self.words = []
+        self._base = []
+        for i, s in enumerate(self._shms):
+            if s is None:
+                continue
+            try:
+                s.close()
+            except Exception:
+                pass
+        try:
+            self._mine.unlink()
+        except Exception:
+            pass
+        self._shms = []
+
+
+def ring(stream_ptr: int, on_gpu: bool, lanes: List[int], pulled: List[int], slot: int, seq: int, clock: int):
+    """After everything queued on the stream so far: publish gradient number ``seq`` of this worker (slot ``slot`` of
+    the inboxes) to the owners whose lanes are given; ``lanes[0]`` must be the lane in owner 0's block."""
+    n = len(lanes)
+    la = (C.c_void_p * n)(*lanes)
+    pv = (C.c_ulonglong * n)(*pulled)
+    rc = _k().dtf_doorbell_ring(C.c_void_p(stream_ptr or 0), 1 if on_gpu else 0, la, pv, n, int(slot), int(seq), int(clock))
+    if rc:
+        raise RuntimeError("doorbell failed (%d)" % rc)
+
+
+class OwnerPump:
+    """The owner's native service thread: applies arriving gradient shards to ``var`` / slots on its own stream."""
+
+    def __init__(self, *, device, owner: int, workers: int, depth: int, n: int, slot_stride: int, var, m, v, inbox,
+                 step, beta_powers, optimizer, ctl_address: int):
+        lib = _k()
+        assert lib.dtf_pump_config_bytes() == C.sizeof(_PumpConfig), "owner_pump.hip and doorbell.py disagree"
+        self.device = torch.device(device)
+        on_gpu = self.device.type == "cuda"
+        self._keep = (var, m, v, inbox, step, beta_powers)
+        self._ticket = torch.zeros(1, dtype=torch.int32, device=self.device) if on_gpu else None
+        cfg = _PumpConfig()
+        cfg.on_gpu, cfg.owner, cfg.workers, cfg.depth = int(on_gpu), int(owner), int(workers), int(depth)
+        is_adam = optimizer.name == "Adam"
+        cfg.optimizer = 0 if is_adam else 1
+        cfg.n, cfg.slot_stride = int(n), int(slot_stride)
+        cfg.var, cfg.m, cfg.v, cfg.inbox = nv.ptr(var), nv.ptr(m), nv.ptr(v), nv.ptr(inbox)
+        cfg.step, cfg.beta_powers = nv.ptr(step), nv.ptr(beta_powers if is_adam else None)
+        cfg.ticket = nv.ptr(self._ticket)
+        if is_adam:
+            cfg.lr, cfg.b1, cfg.b2, cfg.eps, cfg.momentum = optimizer.lr, optimizer.beta1, optimizer.beta2, optimizer.epsilon, 0.0
+        else:
+            cfg.lr, cfg.b1, cfg.b2, cfg.eps, cfg.momentum = optimizer.lr, 0.0, 0.0, 0.0, optimizer.momentum
+        cfg.ctl = ctl_address
+        if on_gpu:
+            with torch.cuda.device(self.device):
+                self._h = lib.dtf_pump_start(C.byref(cfg))
+        else:
+            self._h = lib.dtf_pump_start(C.byref(cfg))
+        if not self._h:
+            raise RuntimeError("cannot start the owner pump")
+
+    def pause(self):
+        rc = _k().dtf_pump_pause(self._h)
+        if rc:
+            raise RuntimeError("owner pump failed (%d)" % rc)
+
+    def resume(self, resync: bool = False):
+        _k().dtf_pump_resume(self._h, 1 if resync else 0)
+
+    def error(self) -> int:
+        return int(_k().dtf_pump_error(self._h)) if self._h else 0
+
+    def stream(self) -> Optional[int]:
+        return _k().dtf_pump_stream(self._h)
+
+    def histogram(self):
+        out = (C.c_longlong * HIST)()
+        _k().dtf_pump_histogram(self._h, out)
+        return {i: int(out[i]) for i in range(HIST) if out[i]}
+
+    def stop(self) -> int:
+        h, self._h = self._h, None
+        return int(_k().dtf_pump_stop(h)) if h else 0
+
+
+def spin_until(pred, timeout_s: float, what: str, check=None):
+    """Poll ``pred`` (a cheap read of shared words) until true; the first polls spin, later ones sleep briefly."""
+    if pred():
+        return 0.0
+    t0 = time.perf_counter()
+    n = 0
+    while not pred():
+        n += 1
+        if n > 50:
+            time.sleep(0.00005 if n < 2000 else 0.0005)
+        if n % 256 == 0:
+            if check is not None:
+                check()
+            if time.perf_counter() - t0 > timeout_s:
+                raise TimeoutError("timed out after %.0f s waiting for %s" % (timeout_s, what))
+    return time.perf_counter() - t0

@@ -31,7 +31,7 @@ for i in range(steps):
         time.sleep(0.05)                       # the straggler
     m.train_step(x[i * 50:(i + 1) * 50], y[i * 50:(i + 1) * 50])
     # how far this worker's clock is ahead of the slowest one, right after the step it was allowed to take
-    lead_at_start.append(strat.clock - 1 - strat.cp0.clock_min("workers"))
+    lead_at_start.append(strat.clock - 1 - strat.min_clock())
 strat.worker_done()
 strat.cp0.barrier("all_done", len(hosts), timeout_s=120)
 if srv.is_chief:

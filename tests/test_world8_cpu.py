@@ -1,8 +1,8 @@
 """World-size-8 rehearsals on CPU: the shapes an 8-GPU node runs (8 flat owners, 8 staleness clocks, 8 replicas
 writing one checkpoint), with gloo / shared memory standing in for RCCL / hipIpc.
 
-* asynchronous training, 8 workers with colocated owners, flat sharding, ``max_staleness=2``: folded control traffic
-  (round trips per step counted), an owner-side sharded checkpoint whose variables straddle owners, and a restore of
+* asynchronous training, 8 workers with colocated owners, flat sharding, ``max_staleness=2``: no control-plane
+  traffic inside a step (round trips per step counted), an owner-side sharded checkpoint whose variables straddle owners, and a restore of
   that checkpoint into a single process, bit-exact, optimizer slots included;
 * synchronous replicas, world 4, bucketed: every replica writes its own data shard; restored into a single process.
 """
@@ -60,6 +60,7 @@ if srv.is_chief:
     strat.shutdown_owners()
 print("RESULT " + json.dumps({"index": index, "global_step": gs, "sum": float(m.store.flat.double().sum()),
                               "calls": calls, "stale_max": max(strat.staleness_hist), "owner_stats": stats,
+                              "hbm": strat.hbm_report(m),
                               "kernel": m.store.variables["dense_1/kernel"].tensor.double().sum().item()}))
 '''
 
@@ -87,12 +88,17 @@ def test_eight_async_workers_flat_owners_checkpoint_round_trip(tmp_path):
     results.sort(key=lambda r: r["index"])
     assert all(r["global_step"] == n * steps for r in results)
     assert len({round(r["sum"], 6) for r in results}) == 1           # everybody pulled the same variables
-    # folded control traffic: queue the requests, collect the replies, publish-the-clock-and-wait = 3 round trips a
-    # step, whatever the number of owners (they share the chief's control server)
-    assert all(c == 3 for r in results for c in r["calls"]), results[0]["calls"]
+    # a training step makes NO control-plane round trip: gradients, parameters, versions, clocks and the shared step
+    # all travel through the peer regions and the doorbell words
+    assert all(c == 0 for r in results for c in r["calls"]), results[0]["calls"]
     assert all(r["stale_max"] <= 2 + (n - 1) * 3 for r in results)
     owners = results[0]["owner_stats"]
     assert len(owners) == n and all(o["version"] == n * steps for o in owners)
+    # sharded storage: no optimizer slots on a worker, exactly 1/8 of the variables and of each slot on an owner
+    for r in results:
+        h = r["hbm"]
+        assert h["worker_slots"] == 0
+        assert h["owner_variables"] * n == h["worker_variables"] and h["owner_slots"] * n == 2 * h["worker_variables"]
 
     # the checkpoint: one data shard per owner, TF names, whole variables although their elements were spread over owners
     prefix = "%s-%d" % (ckpt, n * steps)
