@@ -636,7 +636,7 @@ def run_rank(args) -> None:
             "config": {"model": args.model, "global_batch": global_batch, "batch_per_gpu": B, "seq_len": None,
                        "parallelism": ("dp%d" if args.mode == "sync" else "async-ps%d") % world, "params": model.store.num_params,
                        "optimizer": "adam", "hip_graph": bool(use_graph), "fused_step_kernel": plan is not None,
-                       "allreduce": args.allreduce if multi else None, "allreduce_us": exchange_us,
+                       "allreduce": args.allreduce if (multi and args.mode == "sync") else None, "allreduce_us": exchange_us,
                        "train_loss": logs.get("loss"), "train_acc": logs.get("acc"), "test_acc": test_acc,
                        "eval_steps": n_eval if test_acc is not None else 0,
                        "steady_warmup_steps": steady_windows * 10,

@@ -27,7 +27,62 @@ struct Mailbox {
     bool opened[MBOX_MAX_RANKS] = {};
 };
 
+struct PeerTable {
+    char* ptr[MBOX_MAX_RANKS];
+};
+
+// One launch moves the shards of ALL peers: blockIdx.y is the peer, so the loads (gather) or stores (scatter) of a
+// launch are in flight on every xGMI link of this GPU at once - the links are point-to-point, and a chain of
+// per-peer copies on one stream would use them one at a time.  16 bytes per lane, grid-stride inside a shard.
+// GATHER: dst[j*n .. (j+1)*n) = peer j's region at `off`;  SCATTER: peer j's region at `off` = src[j*n .. (j+1)*n).
+template <bool GATHER>
+__global__ __launch_bounds__(256) void peer_shards_kernel(PeerTable peers, long long off_bytes, char* local, long long n16,
+                                                          long long shard_bytes) {
+    const int j = blockIdx.y;
+    f32x4* remote = reinterpret_cast<f32x4*>(peers.ptr[j] + off_bytes);
+    f32x4* mine = reinterpret_cast<f32x4*>(local + (long long)j * shard_bytes);
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
+        if (GATHER) mine[i] = __builtin_nontemporal_load(remote + i);
+        else __builtin_nontemporal_store(mine[i], remote + i);
+    }
+    if (!GATHER) __threadfence_system();        // the stores are on their way to the peers before the launch ends
+}
+
+int launch_peer_shards(Mailbox* m, bool gather, long long off, void* local, long long shard_bytes, hipStream_t stream) {
+    if (shard_bytes == 0) return 0;
+    if (off < 0 || shard_bytes < 0 || (shard_bytes & 15) || (off & 15) || (reinterpret_cast<uintptr_t>(local) & 15)) return -3;
+    if ((size_t)off + (size_t)shard_bytes > m->bytes) return -3;
+    PeerTable t;
+    for (int r = 0; r < m->world; ++r) {
+        if (!m->peer[r]) return -2;
+        t.ptr[r] = static_cast<char*>(m->peer[r]);
+    }
+    const long long n16 = shard_bytes / 16;
+    long long bx = (n16 + 255) / 256;
+    const long long cap = 2048 / m->world > 1 ? 2048 / m->world : 1;     // ~8 workgroups per CU over all peers
+    if (bx > cap) bx = cap;
+    if (bx < 1) bx = 1;
+    const dim3 grid((unsigned)bx, (unsigned)m->world);
+    if (gather)
+        hipLaunchKernelGGL(peer_shards_kernel<true>, grid, dim3(256), 0, stream, t, off, static_cast<char*>(local), n16, shard_bytes);
+    else
+        hipLaunchKernelGGL(peer_shards_kernel<false>, grid, dim3(256), 0, stream, t, off, static_cast<char*>(local), n16, shard_bytes);
+    DTF_CHECK_LAUNCH();
+    return 0;
+}
+
 }  // namespace
+
+// dst[j * shard_bytes ...] = region of rank j at byte offset `src_off`, for every rank j, in ONE launch on `stream`.
+DTF_API int dtf_mbox_gather(void* h, long long src_off, void* dst, long long shard_bytes, hipStream_t stream) {
+    return launch_peer_shards(static_cast<Mailbox*>(h), true, src_off, dst, shard_bytes, stream);
+}
+
+// region of rank j at byte offset `dst_off` = src[j * shard_bytes ...], for every rank j, in ONE launch on `stream`.
+DTF_API int dtf_mbox_scatter(void* h, long long dst_off, const void* src, long long shard_bytes, hipStream_t stream) {
+    return launch_peer_shards(static_cast<Mailbox*>(h), false, dst_off, const_cast<void*>(src), shard_bytes, stream);
+}
 
 // Allocates and zeroes this rank's region on the current device.  Null on bad arguments or allocation failure.
 DTF_API void* dtf_mbox_create(int rank, int world, long long bytes) {

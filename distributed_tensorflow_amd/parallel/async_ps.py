@@ -898,8 +898,7 @@ class AsyncPSStrategy:
         """One-sided gets of every owner's variable shard straight into the flat buffer, on the current stream."""
         for j in range(self.num_owners):
             self._pulled[j] = self.blocks.version(j)
-            b, e = self.ranges[j][0]
-            self.region.get(j, 0, store.flat[b:e])
+        self.region.gather(0, store.flat)                # owner j's shard is flat[j*S:(j+1)*S]: one launch, all links
         self.versions = list(self._pulled)
         self.last_global_step = self.blocks.global_step()
 
@@ -922,10 +921,8 @@ class AsyncPSStrategy:
         else:
             ctx = _NullContext()
         with ctx:
-            base = 3 * self.slot_len + (w * D + slot) * self.slot_len
-            for j in range(W):
-                b, e = self.ranges[j][0]
-                self.region.put(j, base, store.flat_grad[b:e])
+            # shard j of the gradient into this worker's slot of owner j's inbox: one launch, all links at once
+            self.region.scatter(3 * self.slot_len + (w * D + slot) * self.slot_len, store.flat_grad)
             if on_gpu:
                 self._ev_copied.record(self._comm_stream)
             from .doorbell import ring

@@ -42,6 +42,8 @@ def _k():
         nv.declare(lib, "dtf_mbox_open_peer", [p, C.c_int, p])
         nv.declare(lib, "dtf_mbox_put", [p, C.c_int, ll, p, ll, p])
         nv.declare(lib, "dtf_mbox_get", [p, C.c_int, ll, p, ll, p])
+        nv.declare(lib, "dtf_mbox_gather", [p, ll, p, ll, p])
+        nv.declare(lib, "dtf_mbox_scatter", [p, ll, p, ll, p])
         nv.declare(lib, "dtf_mbox_sync", [p])
         nv.declare(lib, "dtf_mbox_destroy", [p], None)
         _lib = lib
@@ -153,6 +155,43 @@ class PeerRegion:
                 raise RuntimeError("peer get from rank %d failed (%d)" % (peer, rc))
         else:
             dst.reshape(-1).copy_(self._peer_views[peer][src_off:src_off + dst.numel()])
+
+    def gather(self, src_off: int, dst: torch.Tensor):
+        """``dst[j*n:(j+1)*n] = region[j][src_off : src_off + n]`` for every rank ``j`` (``n = dst.numel() / world``).
+        On GPUs one kernel launch reads from all peers at once, so every xGMI link of this GPU carries its shard
+        concurrently; a chain of per-peer copies on one stream would use the point-to-point links one at a time."""
+        n = dst.numel() // self.world
+        if dst.numel() != n * self.world:
+            raise ValueError("gather needs a destination of world * n elements")
+        self._check(dst[:n], src_off)
+        if n == 0:
+            return
+        if self._h is not None and n % 4 == 0 and src_off % 4 == 0:
+            rc = _k().dtf_mbox_gather(self._h, int(src_off) * 4, dst.data_ptr(), n * 4,
+                                      torch.cuda.current_stream(self.device).cuda_stream)
+            if rc:
+                raise RuntimeError("peer gather failed (%d)" % rc)
+            return
+        for j in range(self.world):
+            self.get(j, src_off, dst[j * n:(j + 1) * n])
+
+    def scatter(self, dst_off: int, src: torch.Tensor):
+        """``region[j][dst_off : dst_off + n] = src[j*n:(j+1)*n]`` for every rank ``j``: the one-launch counterpart of
+        ``gather`` (stores to all peers in flight at once)."""
+        n = src.numel() // self.world
+        if src.numel() != n * self.world:
+            raise ValueError("scatter needs a source of world * n elements")
+        self._check(src[:n], dst_off)
+        if n == 0:
+            return
+        if self._h is not None and n % 4 == 0 and dst_off % 4 == 0:
+            rc = _k().dtf_mbox_scatter(self._h, int(dst_off) * 4, src.data_ptr(), n * 4,
+                                       torch.cuda.current_stream(self.device).cuda_stream)
+            if rc:
+                raise RuntimeError("peer scatter failed (%d)" % rc)
+            return
+        for j in range(self.world):
+            self.put(j, dst_off, src[j * n:(j + 1) * n])
 
     def sync(self):
         """Wait until every put / get issued on the current stream has completed (and is visible to its target)."""
