@@ -76,7 +76,7 @@ def parse_args(argv=None):
                          "mixed precision for wide dense layers (bf16 operands, fp32 accumulation)")
     ap.add_argument("--eval", type=int, default=-1,
                     help="after the timed steps, train this many more steps (untimed) and report the accuracy on a held-out "
-                         "test set (-1 = auto: 100 steps, 5 for wide_mlp; 0 = skip)")
+                         "test set (-1 = auto: 100 steps, 60 for wide_mlp; 0 = skip)")
     ap.add_argument("--steady", type=float, default=0.5,
                     help="after --warmup, keep stepping (untimed) for at least this many seconds and until two consecutive "
                          "10-step windows agree within 2 %% (0 = off)")
@@ -453,8 +453,15 @@ def run_rank(args) -> None:
         model = models.wide_mlp(width=args.width, depth=args.depth)
         loss = "sparse_categorical_crossentropy"
         make = lambda n, seed: data.mnist_like(n, seed=seed, device=dev)
-    model.compile(loss=loss, optimizer="adam", metrics=metrics, strategy=strategy, device=dev, seed=0,
+    optimizer = "adam"
+    if args.model == "wide_mlp":
+        from distributed_tensorflow_amd.optimizers import Adam
+        optimizer = Adam(lr=models.wide_mlp_learning_rate(args.width))     # Adam's default rate diverges at this width
+    t_compile = time.perf_counter()
+    model.compile(loss=loss, optimizer=optimizer, metrics=metrics, strategy=strategy, device=dev, seed=0,
                   matmul_dtype=args.matmul)
+    sync_device()
+    t_compile = time.perf_counter() - t_compile
 
     pool = max(1, args.pool)
     # small-batch reference network on one GPU: the whole step (and runs of consecutive steps) is one launch
@@ -568,7 +575,7 @@ def run_rank(args) -> None:
     # ---- test accuracy (untimed): a fixed budget of further training steps, then a held-out set every rank evaluates
     # a slice of (the statistics are summed over ranks)
     test_acc = None
-    n_eval = args.eval if args.eval >= 0 else (5 if args.model == "wide_mlp" else 100)
+    n_eval = args.eval if args.eval >= 0 else (60 if args.model == "wide_mlp" else 100)
     if n_eval > 0:
         run(done, n_eval)
         done += n_eval
@@ -635,7 +642,9 @@ def run_rank(args) -> None:
             "data": "synthetic (device-resident MNIST-shaped inputs, random-init weights)",
             "config": {"model": args.model, "global_batch": global_batch, "batch_per_gpu": B, "seq_len": None,
                        "parallelism": ("dp%d" if args.mode == "sync" else "async-ps%d") % world, "params": model.store.num_params,
-                       "optimizer": "adam", "hip_graph": bool(use_graph), "fused_step_kernel": plan is not None,
+                       "optimizer": "adam", "learning_rate": model.optimizer.lr,
+                       "compile_seconds": t_compile, "device_initialised": bool(getattr(model.store, "device_initialised", False)),
+                       "hip_graph": bool(use_graph), "fused_step_kernel": plan is not None,
                        "allreduce": args.allreduce if (multi and args.mode == "sync") else None, "allreduce_us": exchange_us,
                        "train_loss": logs.get("loss"), "train_acc": logs.get("acc"), "test_acc": test_acc,
                        "eval_steps": n_eval if test_acc is not None else 0,

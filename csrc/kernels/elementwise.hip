@@ -111,3 +111,29 @@ DTF_API int dtf_activation(const float* X, float* Y, long long n, int act, hipSt
     DTF_CHECK_LAUNCH();
     return 0;
 }
+
+// Variable initialisers on the device: x[i] = lo + (hi - lo) * u(seed, i) with u a counter-based uniform in [0, 1)
+// (two avalanche rounds over the 64-bit element index and the seed), so a billion-parameter model is initialised
+// at HBM speed instead of drawing on the host and copying (Keras' glorot_uniform / he_uniform behind the layers of
+// /root/reference/example.py:150-154 are uniform distributions; only their bounds differ).
+__global__ __launch_bounds__(256) void init_uniform_kernel(float* __restrict__ x, long long n, uint32_t seed, float lo, float hi) {
+#pragma clang fp contract(off)      // multiply and add round separately: the same bits as the CPU implementation
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const float span = hi - lo;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t a = dtf_mix32((uint32_t)i * 0x9E3779B1u + seed);
+        const uint32_t r = dtf_mix32(a ^ ((uint32_t)((unsigned long long)i >> 32) * 0x85EBCA6Bu + 0x27D4EB2Fu));
+        const float u = (float)(r >> 8) * (1.0f / 16777216.0f);
+        const float su = span * u;
+        x[i] = lo + su;
+    }
+}
+
+DTF_API int dtf_init_uniform(float* x, long long n, uint32_t seed, float lo, float hi, hipStream_t stream) {
+    if (n <= 0) return 0;
+    long long g = (n + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(init_uniform_kernel, dim3((unsigned)g), dim3(256), 0, stream, x, n, seed, lo, hi);
+    DTF_CHECK_LAUNCH();
+    return 0;
+}

@@ -36,15 +36,24 @@ def mnist_mlp(hidden: int = 128, dropout: float = 0.3, num_classes: int = 10, in
 def wide_mlp(width: int = 16384, depth: int = 5, num_classes: int = 10, input_dim: int = 784,
              dropout: float = 0.0) -> Sequential:
     """``depth`` hidden layers of ``width`` units: 784*w + (depth-1)*w^2 + 10*w parameters
-    (1.087e9 at the defaults)."""
+    (1.087e9 at the defaults).  The ReLU layers use He-uniform initial values (the activation scale then does not
+    depend on depth); train it with ``wide_mlp_learning_rate(width)``."""
     m = Sequential(name="wide_mlp")
-    m.add(Dense(width, input_dim=input_dim, activation="relu"))
+    m.add(Dense(width, input_dim=input_dim, activation="relu", kernel_initializer="he_uniform"))
     for _ in range(depth - 1):
         if dropout > 0:
             m.add(Dropout(dropout))
-        m.add(Dense(width, activation="relu"))
+        m.add(Dense(width, activation="relu", kernel_initializer="he_uniform"))
     m.add(Dense(num_classes, activation="softmax"))
     return m
+
+
+def wide_mlp_learning_rate(width: int, base_lr: float = 1e-3, base_width: int = 128) -> float:
+    """Adam's step per weight is about the learning rate whatever the gradient's size, and a unit with ``width``
+    inputs adds up ``width`` such steps: the rate that works at the reference's width 128
+    (/root/reference/example.py:150-154,168) has to shrink in proportion for the pre-activations of a wide layer to
+    move as they do there (1e-3 at 16384 inputs changes them by ~16 per step and the loss diverges)."""
+    return base_lr * min(1.0, float(base_width) / float(width))
 
 
 def mnist_cnn(num_classes: int = 10, dropout: float = 0.3) -> Sequential:

@@ -74,6 +74,7 @@ def kernels():
         "dtf_dropout": [c_p, c_p, c_ll, c_f, c_u32, c_p, c_p],
         "dtf_xor_data": [c_p, c_p, c_i, c_i, c_u32, c_p],
         "dtf_scale": [c_p, c_ll, c_f, c_p],
+        "dtf_init_uniform": [c_p, c_ll, c_u32, c_f, c_f, c_p],
         "dtf_activation": [c_p, c_p, c_ll, c_i, c_p],
         "dtf_softmax_rows": [c_p, c_p, c_i, c_i, c_p],
         "dtf_im2col": [c_p, c_p] + [c_i] * 12 + [c_p],

@@ -427,6 +427,27 @@ def step_advance(step, beta_powers=None, beta1=0.9, beta2=0.999):
     return step
 
 
+def init_uniform_(x: torch.Tensor, seed: int, lo: float, hi: float) -> torch.Tensor:
+    """Fill ``x`` (flat fp32) with ``lo + (hi - lo) * u(seed, i)``, ``u`` a counter-based uniform in [0, 1): the same
+    values on the GPU (one HBM-speed launch) and on the CPU."""
+    n = x.numel()
+    if x.is_cuda:
+        nv.require_f32_contig(x)
+        nv.check(nv.kernels().dtf_init_uniform(nv.ptr(x), n, int(seed) & _M32, float(lo), float(hi), nv.stream_ptr()),
+                 "dtf_init_uniform")
+        return x
+    out = x.view(-1)
+    chunk = 1 << 22
+    for b in range(0, n, chunk):
+        i = torch.arange(b, min(n, b + chunk), dtype=torch.int64)
+        a = _mix32((((i & _M32) * 0x9E3779B1) + (int(seed) & _M32)) & _M32)
+        r = _mix32(a ^ ((((i >> 32) * 0x85EBCA6B) + 0x27D4EB2F) & _M32))
+        u = (r >> 8).to(torch.float32) * (1.0 / 16777216.0)
+        lo32, hi32 = torch.tensor(lo, dtype=torch.float32), torch.tensor(hi, dtype=torch.float32)
+        out[b:b + i.numel()] = lo32 + (hi32 - lo32) * u
+    return x
+
+
 def xor_data(n, bits, seed, device):
     """Device-side generator of the XOR task of /root/reference/example.py:24-48."""
     x = torch.empty((n, 2 * bits), dtype=torch.float32, device=device)

@@ -45,6 +45,36 @@ def glorot_uniform(shape: Sequence[int], generator: Optional[torch.Generator] = 
     return (torch.rand(tuple(shape), generator=generator, dtype=torch.float32) * 2.0 - 1.0) * limit
 
 
+def _fans(shape: Sequence[int]) -> Tuple[int, int]:
+    if len(shape) == 2:
+        return int(shape[0]), int(shape[1])
+    if len(shape) == 4:
+        rf = shape[0] * shape[1]
+        return int(shape[2] * rf), int(shape[3] * rf)
+    n = int(math.prod(shape)) if shape else 1
+    return n, n
+
+
+def he_uniform(shape: Sequence[int], generator: Optional[torch.Generator] = None) -> torch.Tensor:
+    """Keras ``he_uniform``: U(-l, l) with l = sqrt(6 / fan_in) - keeps the activation scale of ReLU stacks constant
+    with depth, which very wide layers need."""
+    limit = math.sqrt(6.0 / float(_fans(shape)[0]))
+    return (torch.rand(tuple(shape), generator=generator, dtype=torch.float32) * 2.0 - 1.0) * limit
+
+
+def uniform_limit(initializer, shape) -> Optional[float]:
+    """``l`` when ``initializer`` draws from U(-l, l) (0 for zeros); None for anything else.  What the device-side
+    initialisation of large models needs to know about an initializer."""
+    fan_in, fan_out = _fans(shape)
+    if initializer is glorot_uniform:
+        return math.sqrt(6.0 / float(fan_in + fan_out))
+    if initializer is he_uniform:
+        return math.sqrt(6.0 / float(fan_in))
+    if initializer is zeros:
+        return 0.0
+    return None
+
+
 def zeros(shape, generator=None):
     return torch.zeros(tuple(shape), dtype=torch.float32)
 
@@ -53,7 +83,12 @@ def ones(shape, generator=None):
     return torch.ones(tuple(shape), dtype=torch.float32)
 
 
-INITIALIZERS: Dict[str, Callable] = {"glorot_uniform": glorot_uniform, "zeros": zeros, "ones": ones}
+INITIALIZERS: Dict[str, Callable] = {"glorot_uniform": glorot_uniform, "he_uniform": he_uniform, "zeros": zeros,
+                                     "ones": ones}
+
+# models with more parameters than this are initialised by a kernel on their device (a counter-based generator
+# keyed by seed and variable index) instead of the host generator followed by a host-to-device copy
+DEVICE_INIT_MIN_PARAMS = 1 << 26
 
 
 def get_initializer(spec) -> Callable:
@@ -126,8 +161,12 @@ class VariableStore:
     def num_params(self) -> int:
         return sum(v.numel for v in self.trainable)
 
-    def finalize(self, device, seed: Optional[int] = None, pad_multiple: int = ALIGN) -> "VariableStore":
-        """Lay out the flat buffers on ``device`` and run the initializers (host RNG, then one H2D copy)."""
+    def finalize(self, device, seed: Optional[int] = None, pad_multiple: int = ALIGN,
+                 device_init: Optional[bool] = None) -> "VariableStore":
+        """Lay out the flat buffers on ``device`` and run the initializers: the host generator and one host-to-device
+        copy for ordinary models (the values then do not depend on the device), a device-side counter-based generator
+        for models above ``DEVICE_INIT_MIN_PARAMS`` parameters whose initializers are uniform (``device_init`` forces
+        either): a billion parameters take milliseconds instead of a 4 GB host pass and copy."""
         if self.finalized:
             return self
         self.device = torch.device(device)
@@ -142,10 +181,22 @@ class VariableStore:
             gen.seed()
         else:
             gen.manual_seed(int(seed))
-        host = torch.zeros(self.flat_len, dtype=torch.float32)
-        for v in self.trainable:
-            host[v.offset:v.offset + v.numel] = v.initializer(v.shape, gen).reshape(-1)
-        self.flat = host.to(self.device)
+        limits = [uniform_limit(v.initializer, v.shape) for v in self.trainable]
+        if device_init is None:
+            device_init = self.num_params >= DEVICE_INIT_MIN_PARAMS
+        self.device_initialised = bool(device_init) and all(l is not None for l in limits)
+        if self.device_initialised:
+            from .ops import functional as F
+            base = int(gen.initial_seed()) & 0x7FFFFFFF
+            self.flat = torch.zeros(self.flat_len, dtype=torch.float32, device=self.device)
+            for k, (v, l) in enumerate(zip(self.trainable, limits)):
+                if l:
+                    F.init_uniform_(self.flat[v.offset:v.offset + v.numel], base + 7919 * (k + 1), -l, l)
+        else:
+            host = torch.zeros(self.flat_len, dtype=torch.float32)
+            for v in self.trainable:
+                host[v.offset:v.offset + v.numel] = v.initializer(v.shape, gen).reshape(-1)
+            self.flat = host.to(self.device)
         self.flat_grad = torch.zeros(self.flat_len, dtype=torch.float32, device=self.device)
         for v in self.trainable:
             v.tensor = self.flat[v.offset:v.offset + v.numel].view(v.shape)

@@ -208,3 +208,14 @@ def test_dense_forward_splits_a_long_k_with_few_output_tiles(gpu_device):
     torch.testing.assert_close(yd, F.dense_forward(x, w, b, 1, keep=0.7, seed=31, step=step), rtol=1e-5, atol=1e-5)
     assert 0.25 < (yd == 0).float().mean() < 0.9                       # ReLU zeros plus 30 % dropped
     assert F.dense_fwd_workspace_floats(65536, 128, 784) == 0          # plenty of tiles: never split
+
+
+def test_device_initialiser_matches_the_cpu_generator():
+    """``init_uniform_``: the HIP kernel and the CPU implementation of the counter-based generator agree bit for bit
+    (also past element 2^32 is covered by the same formula; here a range with an odd length)."""
+    from distributed_tensorflow_amd.ops import functional as F
+    n = 1_000_003
+    g = F.init_uniform_(torch.empty(n, device="cuda"), 12345, -0.037, 0.037)
+    c = F.init_uniform_(torch.empty(n), 12345, -0.037, 0.037)
+    assert torch.equal(g.cpu(), c)
+    assert float(g.min()) >= -0.037 and float(g.max()) < 0.037 and abs(float(g.mean())) < 1e-3

@@ -164,3 +164,42 @@ def test_matmul_dtype_switch_is_validated_and_harmless_on_cpu():
             xor_mlp().compile(matmul_dtype="fp16")
     finally:
         F.set_gemm_split_products(0)
+
+
+def test_he_uniform_and_device_side_initialisation():
+    """He-uniform bounds; the counter-based initialiser that large models use on their device gives U(-l, l) with the
+    same bounds, is a pure function of (seed, variable, element) and leaves biases at zero."""
+    import math
+    from distributed_tensorflow_amd.layers import Dense
+    from distributed_tensorflow_amd.models import Sequential
+    from distributed_tensorflow_amd.ops import functional as F
+    from distributed_tensorflow_amd.variables import he_uniform
+    w = he_uniform((600, 50), torch.Generator().manual_seed(0))
+    lim = math.sqrt(6.0 / 600)
+    assert w.abs().max() <= lim and w.abs().max() > 0.95 * lim and abs(w.mean()) < 0.01
+    a = F.init_uniform_(torch.empty(100000), 7, -0.5, 0.5)
+    b = F.init_uniform_(torch.empty(100000), 7, -0.5, 0.5)
+    c = F.init_uniform_(torch.empty(100000), 8, -0.5, 0.5)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    assert a.min() >= -0.5 and a.max() < 0.5 and abs(a.mean()) < 0.01 and abs(a.std() - 1 / math.sqrt(12)) < 0.01
+    # neighbouring elements are uncorrelated
+    assert abs(torch.corrcoef(torch.stack([a[:-1], a[1:]]))[0, 1]) < 0.02
+
+    def make():
+        m = Sequential([Dense(64, input_dim=32, activation="relu", kernel_initializer="he_uniform"), Dense(10, activation="softmax")])
+        m.build(device="cpu", seed=3)
+        return m
+    m1 = make()
+    assert not m1.store.device_initialised
+    from distributed_tensorflow_amd.variables import VariableStore
+    st = VariableStore()
+    k = st.create("dense_1/kernel", (32, 64), "he_uniform")
+    bia = st.create("dense_1/bias", (64,), "zeros")
+    st.finalize("cpu", seed=3, device_init=True)
+    assert st.device_initialised
+    assert k.tensor.abs().max() <= math.sqrt(6.0 / 32) and k.tensor.std() > 0.2 and float(bia.tensor.abs().sum()) == 0.0
+    st2 = VariableStore()
+    k2 = st2.create("dense_1/kernel", (32, 64), "he_uniform")
+    st2.create("dense_1/bias", (64,), "zeros")
+    st2.finalize("cpu", seed=3, device_init=True)
+    assert torch.equal(k.tensor, k2.tensor)
