@@ -147,17 +147,14 @@ class ModelEngine:
     def _sharded_sync_save(self) -> bool:
         """Synchronous replicas of a model large enough to be sharded: every replica writes its share of the files."""
         st = self.model.strategy
-        return bool(getattr(st, "collective_checkpoint", False)) and st.world_size > 1 and not getattr(st, "replicated", True)
+        return bool(getattr(st, "collective_checkpoint", False)) and not getattr(st, "replicated", True)
 
     def make_saver(self, max_to_keep: int = 5):
         st = self.model.strategy
         store = self.model.store
         if self._sharded_sync_save():
-            # one data shard per replica: whole variables (with their optimizer slots) dealt out byte-balanced
-            from .cluster import ByteBalancedPlacement
-            placement = ByteBalancedPlacement().assign([(v.name, v.numel * 4) for v in store.trainable], st.world_size)
-            return saver_mod.Saver(store, self.model.optimizer, max_to_keep=max_to_keep, placement=placement,
-                                   num_shards=st.world_size)
+            # one data shard per replica: the strategy deals its buckets (whole variables with their slots) out
+            return saver_mod.Saver(store, self.model.optimizer, max_to_keep=max_to_keep, num_shards=st.world_size)
         placement = getattr(st, "placement", None) or {}
         shards = getattr(st, "num_owners", 1) if placement and not all(v == -1 for v in placement.values()) else 1
         return saver_mod.Saver(store, self.model.optimizer, max_to_keep=max_to_keep,
@@ -175,14 +172,11 @@ class ModelEngine:
             return prefix
         if self._sharded_sync_save():
             # every replica holds all variables (all-gathered each step) but only its shards of the optimizer slots:
-            # complete the slots over xGMI, then each replica writes the variables dealt to it - the device-to-host
-            # copies and the file writes run in parallel on all replicas instead of funnelling through the chief
-            st.gather_slots(self.model)
-            saver.save(save_path, global_step=step, only_shard=st.rank)
-            st.comm.barrier()
+            # each bucket's slot shards are gathered to the one replica that writes that bucket, and the device-to-host
+            # copies and file writes run in parallel on all replicas instead of funnelling through the chief
+            st.save_sharded(self.model, prefix)
             if st.rank == 0:
-                saver.finish_sharded_save(prefix)
-            st.comm.barrier()
+                saver._record(prefix)
             return prefix
         if hasattr(st, "gather_slots"):
             st.gather_slots(self.model)          # collective: every replica takes part

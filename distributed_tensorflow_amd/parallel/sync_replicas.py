@@ -9,9 +9,11 @@ semantics but replaces the PS round trip by collectives on contiguous ranges:
     reduce-scatter(grad bucket)  ->  fused Adam on the 1/N shard this rank owns
                                  ->  all-gather(updated parameter bucket)
 
-Each rank is therefore the "parameter server" (owner) of 1/N of every bucket: the
-optimizer state it touches and the apply work are sharded N ways, and every xGMI link
-carries 1/N of the data in each collective.  Buckets are built in backward order and
+Each rank is therefore the "parameter server" (owner) of 1/N of every bucket: the apply work is
+sharded N ways, the optimizer slots EXIST only as those shards (a rank allocates 1/N of each slot
+buffer, as a reference worker holds no optimizer state at all: /root/reference/example.py:136-139,
+168-170 put it on the ps tasks), and every xGMI link carries 1/N of the data in each collective.
+A checkpoint gathers each bucket's slot shards to the one replica that writes that bucket.  Buckets are built in backward order and
 their reduce-scatter is issued (asynchronously, on RCCL's stream) as soon as the last
 gradient of the bucket has been produced, so communication overlaps the remaining
 backward GEMMs.  Collectives are large by default (64 MiB buckets): ring collectives over
@@ -37,7 +39,7 @@ from .comm import Communicator
 
 
 class _Bucket:
-    __slots__ = ("begin", "end", "layers", "pending", "work", "shard", "shard_begin", "shard_end")
+    __slots__ = ("begin", "end", "layers", "pending", "work", "shard", "shard_begin", "shard_end", "slot_off", "writer")
 
     def __init__(self, begin: int, end: int):
         self.begin, self.end = begin, end
@@ -46,6 +48,8 @@ class _Bucket:
         self.work = None
         self.shard: Optional[torch.Tensor] = None
         self.shard_begin = self.shard_end = 0
+        self.slot_off = 0           # where this bucket's shard starts in the rank's slot-shard buffers
+        self.writer = 0             # the replica that writes this bucket's variables and slots into checkpoints
 
 
 class SyncReplicasStrategy:
@@ -73,6 +77,12 @@ class SyncReplicasStrategy:
         self._layer_bucket: Dict[int, _Bucket] = {}
         # exercise the real collectives even with one rank (GPU-box test of the RCCL path)
         self.force = os.environ.get("DTF_FORCE_COLLECTIVES", "0") == "1"
+        self.slot_shards: Dict[str, torch.Tensor] = {}     # sharded mode: this rank's 1/N of every optimizer slot
+        self.slot_shard_len = 0
+
+    #: ``compile`` leaves the optimizer slots to ``prepare``: full-length on every replica when the apply is
+    #: replicated, 1/N per rank when it is sharded
+    owns_optimizer_state = True
 
     # ------------------------------------------------------------------ setup
     def var_alignment(self) -> int:
@@ -91,11 +101,12 @@ class SyncReplicasStrategy:
         # the chief's initial values win; everyone else receives them
         self.comm.broadcast(store.flat, 0)
         self.comm.broadcast(store.global_step, 0)
-        for s in store.slots.values():
-            self.comm.broadcast(s, 0)
         self._device = store.device
         self.replicated = store.flat_len * 4 <= self.allreduce_below_bytes
         if self.replicated:
+            model.optimizer.create_slots(store)
+            for s in store.slots.values():
+                self.comm.broadcast(s, 0)
             self.buckets = []
             self._layer_bucket = {}
             model._after_layer_backward = None
@@ -107,7 +118,24 @@ class SyncReplicasStrategy:
                 self.p2p = P2PAllReduce(store.flat_len, store.device, group=self.comm.group)
             return
         self._build_buckets(model)
+        self._create_slot_shards(model)
         model._after_layer_backward = self._on_layer_backward if self.overlap else None
+
+    def _create_slot_shards(self, model):
+        """The optimizer slots of the shards this rank owns - the only place they exist."""
+        from .. import optimizers
+        store, opt = model.store, model.optimizer
+        self.slot_shards = {}
+        names = ["m", "v"] if isinstance(opt, optimizers.Adam) else (["momentum"] if getattr(opt, "momentum", 0.0) > 0.0 else [])
+        for name in names:
+            self.slot_shards[name] = torch.zeros(max(self.slot_shard_len, 1), dtype=torch.float32, device=store.device)
+        if isinstance(opt, optimizers.Adam) and not getattr(store, "_beta_powers_initialised", False):
+            store.beta_powers.copy_(optimizers.initial_beta_powers(opt, store.beta_powers.device))
+            store._beta_powers_initialised = True
+
+    def slot_bytes_per_rank(self) -> int:
+        """Device bytes of optimizer state this rank holds (sharded mode: 1/N of every slot)."""
+        return sum(t.numel() * 4 for t in self.slot_shards.values())
 
     def _build_buckets(self, model):
         store = model.store
@@ -130,6 +158,8 @@ class SyncReplicasStrategy:
                 cur = None
         if self.buckets:
             self.buckets[-1].begin = 0
+        off = 0
+        load = [0] * W
         for b in self.buckets:
             n = (b.end - b.begin) // W
             assert n * W == b.end - b.begin
@@ -137,6 +167,11 @@ class SyncReplicasStrategy:
             b.shard_end = b.shard_begin + n
             b.shard = torch.empty(n, dtype=torch.float32, device=store.device)
             b.pending = len(b.layers)
+            b.slot_off = off
+            off += n
+            b.writer = load.index(min(load))        # checkpoint writers: buckets dealt out byte-balanced (greedy)
+            load[b.writer] += b.end - b.begin
+        self.slot_shard_len = off
 
     # ------------------------------------------------------------------ per step
     def _launch(self, b: _Bucket, store):
@@ -240,8 +275,8 @@ class SyncReplicasStrategy:
                 b.work.wait()
             b.work = None
             # owner applies on its shard: var/slots are the flat ranges, the gradient is the reduced shard
-            model.optimizer.apply(_ShardView(store, b), 0, b.shard_end - b.shard_begin, grad_scale=scale,
-                                  grad=b.shard, step=store.global_step)
+            model.optimizer.apply(_ShardView(store, b, self.slot_shards), 0, b.shard_end - b.shard_begin,
+                                  grad_scale=scale, grad=b.shard, step=store.global_step)
             full = store.flat[b.begin:b.end]
             mine = store.flat[b.shard_begin:b.shard_end]
             if self.world_size == 1 and not self.force:
@@ -272,26 +307,127 @@ class SyncReplicasStrategy:
             self.p2p.check()
 
     def broadcast_state(self, model):
-        """Chief-initialises / others-wait: the chief's variables, slots and step win on every replica."""
+        """Chief-initialises / others-wait: the chief's variables, slots and step win on every replica.  Sharded
+        slots are not broadcast: after a restore every replica reads its own shards from the checkpoint files, else
+        they are zero everywhere."""
         self.check_exchange()
         store = model.store
         self.comm.broadcast(store.flat, 0)
         self.comm.broadcast(store.global_step, 0)
         self.comm.broadcast(store.beta_powers, 0)
-        for name in sorted(store.slots):
-            self.comm.broadcast(store.slots[name], 0)
+        if self.replicated or not self.buckets:
+            for name in sorted(store.slots):
+                self.comm.broadcast(store.slots[name], 0)
+            return
+        prefix = [getattr(model, "_restored_from", None) if self.rank == 0 else None]
+        if self.world_size > 1:
+            import torch.distributed as dist
+            dist.broadcast_object_list(prefix, src=0, group=self.comm.group)
+        if prefix[0]:
+            self.restore_slot_shards(model, prefix[0])
+        else:
+            for t in self.slot_shards.values():
+                t.zero_()
+
+    def _bucket_variables(self, model, b: _Bucket):
+        return [v for layer in b.layers for v in layer.variables]
+
+    def restore_slot_shards(self, model, prefix: str):
+        """This rank's slices of the optimizer slots, read from the checkpoint ``prefix`` (every replica for itself)."""
+        from ..saver import BundleReader
+        names = getattr(model.optimizer, "slot_checkpoint_names", {})
+        with BundleReader(prefix) as r:
+            for b in self.buckets:
+                n = b.shard_end - b.shard_begin
+                for v in self._bucket_variables(model, b):
+                    lo, hi = max(v.offset, b.shard_begin), min(v.offset + v.numel, b.shard_end)
+                    if lo >= hi:
+                        continue
+                    for slot, suffix in names.items():
+                        key = "%s/%s" % (v.name, suffix)
+                        if slot in self.slot_shards and r.has_tensor(key):
+                            dst = self.slot_shards[slot][b.slot_off + lo - b.shard_begin:b.slot_off + hi - b.shard_begin]
+                            dst.copy_(r.get_tensor(key).reshape(-1)[lo - v.offset:hi - v.offset])
+
+    def _gather_bucket_slot(self, b: _Bucket, name: str, dst_rank: Optional[int]):
+        """The whole slot range ``[b.begin, b.end)`` on ``dst_rank`` (None: on every replica); None elsewhere."""
+        import torch.distributed as dist
+        n = b.shard_end - b.shard_begin
+        mine = self.slot_shards[name][b.slot_off:b.slot_off + n]
+        W = self.world_size
+        if W == 1:
+            return mine
+        if dst_rank is None:
+            full = torch.empty(n * W, dtype=torch.float32, device=mine.device)
+            self.comm.all_gather(full, mine)
+            return full
+        staged = self.comm.backend == "gloo" and mine.is_cuda
+        src = mine.cpu() if staged else mine
+        if self.rank == dst_rank:
+            full = torch.empty(n * W, dtype=torch.float32, device=src.device)
+            dist.gather(src, [full[r * n:(r + 1) * n] for r in range(W)], dst=dst_rank, group=self.comm.group)
+            return full
+        dist.gather(src, None, dst=dst_rank, group=self.comm.group)
+        return None
+
+    def save_sharded(self, model, prefix: str):
+        """Collective.  Every replica writes data shard ``rank`` of the checkpoint ``prefix``: the variables of the
+        buckets dealt to it, with their optimizer slots, which are gathered - bucket by bucket, to that one writer,
+        not to everybody - from the ranks holding the shards.  The chief adds the step and merges the index."""
+        from ..saver import BundleWriter, merge_shards
+        self.check_exchange()
+        store, opt = model.store, model.optimizer
+        names = getattr(opt, "slot_checkpoint_names", {})
+        w = BundleWriter(prefix, self.world_size, only_shard=self.rank)
+        try:
+            for b in self.buckets:
+                mine = b.writer == self.rank
+                if mine:
+                    for v in self._bucket_variables(model, b):
+                        w.add(v.name, v.tensor, self.rank)
+                for slot in sorted(self.slot_shards):
+                    full = self._gather_bucket_slot(b, slot, b.writer)
+                    if mine:
+                        for v in self._bucket_variables(model, b):
+                            t = full[v.offset - b.begin:v.offset - b.begin + v.numel].view(v.shape)
+                            w.add("%s/%s" % (v.name, names.get(slot, slot)), t, self.rank)
+                    del full
+            if self.rank == 0:
+                for v in store.variables.values():
+                    if not v.trainable:
+                        w.add(v.name, v.tensor, 0)
+                w.add("global_step", store.global_step.view(()), 0)
+                if getattr(opt, "name", "") == "Adam":
+                    w.add("beta1_power", store.beta_powers[0], 0)
+                    w.add("beta2_power", store.beta_powers[1], 0)
+            w.finish()
+        except Exception:
+            w.abort()
+            raise
+        self.comm.barrier()
+        if self.rank == 0:
+            merge_shards(prefix, self.world_size)
+        self.comm.barrier()
+        return prefix
+
+    def full_slots(self, model) -> Dict[str, torch.Tensor]:
+        """Collective: complete optimizer-slot buffers in the flat layout, on every replica (tests, inspection; a
+        training run never needs them)."""
+        store = model.store
+        if self.replicated or not self.buckets:
+            return dict(store.slots)
+        out = {}
+        for name in sorted(self.slot_shards):
+            full = torch.zeros(store.flat_len, dtype=torch.float32, device=store.device)
+            for b in self.buckets:
+                full[b.begin:b.end].copy_(self._gather_bucket_slot(b, name, None))
+            out[name] = full
+        return out
 
     def gather_slots(self, model):
-        """Collective: make every replica's optimizer-slot buffers complete (each replica only updates the
-        slots of the shards it owns), so that the chief can write a full checkpoint."""
+        """Collective no-op kept for callers that checkpoint through the chief: a replicated apply keeps every slot
+        complete on every replica; sharded slots are written by ``save_sharded``."""
         self.check_exchange()                             # never checkpoint past a failed gradient exchange
-        if self.world_size == 1 or self.replicated:      # replicated apply keeps every slot complete everywhere
-            return
-        store = model.store
-        for name in sorted(store.slots):
-            s = store.slots[name]
-            for b in self.buckets:
-                self.comm.all_gather(s[b.begin:b.end], s[b.shard_begin:b.shard_end])
 
     def agree(self, flag: bool) -> bool:
         """The chief's boolean decision, on every replica (one tiny broadcast)."""
@@ -307,9 +443,10 @@ class SyncReplicasStrategy:
 class _ShardView:
     """Presents one bucket shard of a VariableStore as a tiny store so ``Optimizer.apply`` runs on it unchanged."""
 
-    def __init__(self, store, bucket: _Bucket):
+    def __init__(self, store, bucket: _Bucket, slot_shards):
         self._store = store
         self._b = bucket
+        self._slots = slot_shards
         self.flat = store.flat[bucket.shard_begin:bucket.shard_end]
         self.flat_grad = None
         self.flat_len = bucket.shard_end - bucket.shard_begin
@@ -317,4 +454,5 @@ class _ShardView:
         self.beta_powers = store.beta_powers
 
     def slot(self, name: str) -> torch.Tensor:
-        return self._store.slot(name)[self._b.shard_begin:self._b.shard_end]
+        b = self._b
+        return self._slots[name][b.slot_off:b.slot_off + b.shard_end - b.shard_begin]

@@ -91,3 +91,63 @@ def test_sync_replicas_matches_single_process(bucket_bytes, allreduce_below, wor
     logs = res[0][3]
     ref_logs = m.read_stats()
     assert abs(logs["loss"] - ref_logs["loss"]) < 1e-4
+
+
+def _resume_worker(rank, world, port, ckpt, phase, out_q):
+    sys.path.insert(0, ROOT)
+    torch.set_num_threads(1)
+    from distributed_tensorflow_amd.data import mnist_like
+    from distributed_tensorflow_amd.engine import ModelEngine
+    from distributed_tensorflow_amd.layers import Dense
+    from distributed_tensorflow_amd.models import Sequential
+    from distributed_tensorflow_amd.parallel import Communicator, SyncReplicasStrategy, init_process_group
+    init_process_group("gloo", rank=rank, world_size=world, master_addr="127.0.0.1", master_port=port)
+    m = Sequential([Dense(32, input_dim=784, activation="relu"), Dense(32, activation="relu"),
+                    Dense(10, activation="softmax")])
+    strat = SyncReplicasStrategy(Communicator(), bucket_bytes=4096, allreduce_below_bytes=0)       # sharded apply
+    m.compile(loss="sparse_categorical_crossentropy", optimizer="adam", strategy=strat, device="cpu", seed=5 + rank + 10 * phase)
+    assert not m.store.slots and strat.slot_bytes_per_rank() * world == 2 * m.store.flat_len * 4
+    eng = ModelEngine(m)
+    saver = eng.make_saver()
+    x, y = mnist_like(64 * world, seed=3)
+    xs, ys = x[rank * 64:(rank + 1) * 64], y[rank * 64:(rank + 1) * 64]
+    if phase == 0:
+        for _ in range(3):
+            m.train_step(xs, ys)
+        eng.save_checkpoint(saver, ckpt, 3)
+    else:
+        if rank == 0:                       # the chief restores; everybody else receives / reads its own slot shards
+            assert eng.restore_checkpoint(saver, ckpt + "-3") == 3
+        eng.synchronize_state(rank == 0)
+    for _ in range(3):
+        m.train_step(xs, ys)
+    slots = strat.full_slots(m)
+    out_q.put((rank, m.store.flat.clone().numpy(), slots["v"].clone().numpy(), m.global_step))
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_slots_resume_bit_exact(tmp_path):
+    """Sharded apply, world 2: a run that is checkpointed after 3 steps and continued equals, bit for bit, a run by
+    fresh processes that restore that checkpoint - the variables broadcast from the chief, the optimizer-slot shards
+    read by every replica for itself from the files the bucket writers produced."""
+    world = 2
+    ckpt = str(tmp_path / "model.ckpt")
+    finals = []
+    for phase in (0, 1):
+        port = _free_port()
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_resume_worker, args=(r, world, port, ckpt, phase, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        assert all(r[3] == 6 for r in res)
+        finals.append(res[0])
+        assert all((res[0][1] == r[1]).all() for r in res[1:])
+    assert (finals[0][1] == finals[1][1]).all()          # variables
+    assert (finals[0][2] == finals[1][2]).all() and float(abs(finals[0][2]).sum()) > 0       # Adam's v
