@@ -15,12 +15,16 @@ Lets a script written like /root/reference/example.py run almost unchanged::
         sess.run([accuracy, loss, summ, train_step], feed_dict={input_: bx, labels: by, K.learning_phase(): 1})
 
 There is no tracing compiler behind this: symbolic nodes only *describe* the model.  On the
-first session the graph is lowered once onto the kernel-launch engine - the chain of layer
-nodes becomes a :class:`~distributed_tensorflow_amd.models.Sequential`, the loss expression is
-matched to a fused loss kernel, the accuracy expression to the metric the same kernel
-produces - and ``sess.run`` of the training op is the same fixed sequence of HIP kernel
-launches as ``model.train_step``.  Other expressions (``tf.round``, ``tf.equal``...) are
-evaluated eagerly for fetches that are not on the training path.
+first session the graph is lowered once onto the kernel-launch engine.  The fast path: a chain
+of layer nodes on one placeholder becomes a :class:`~distributed_tensorflow_amd.models.Sequential`,
+the loss expression is matched to a fused loss kernel, the accuracy expression to the metric the
+same kernel produces - and ``sess.run`` of the training op is the same fixed sequence of HIP
+kernel launches as ``model.train_step``.  Any other graph - several placeholders, skip
+connections, several losses added up - becomes a
+:class:`~distributed_tensorflow_amd.models.graph_model.GraphModel`: the same kernels behind
+``torch.autograd.Function`` wrappers, differentiated in reverse mode like ``tf.gradients`` does
+behind ``minimize`` (/root/reference/example.py:170).  Other expressions (``tf.round``,
+``tf.equal``...) are evaluated eagerly for fetches that are not on the training path.
 """
 from __future__ import annotations
 
@@ -375,10 +379,15 @@ class GraphEngine(ModelEngine):
     def _lower(self):
         if self.train_op is None:
             raise ValueError("the graph has no training op (optimizer.minimize(loss) was never called)")
-        loss_name, labels, preds = self._match_loss(self.loss_node)
-        self.labels, self.preds = labels, preds
+        self.dag = False
         self.lowered: Dict[Tensor, Any] = {}
-        chain, node = self._lower_chain(preds)
+        try:
+            loss_name, labels, preds = self._match_loss(self.loss_node)
+            self.labels, self.preds = labels, preds
+            chain, node = self._lower_chain(preds)
+        except NotImplementedError:
+            # not a chain on one placeholder with one of the fused losses: differentiate the graph as it is
+            return self._lower_dag()
         self.input = node
         if node.shape is None or len(node.shape) < 2:
             raise ValueError("input placeholder needs a (None, features...) shape")
@@ -397,6 +406,67 @@ class GraphEngine(ModelEngine):
                       strategy=strategy, device=_pick_device(), seed=self.graph.__dict__.get("seed"))
         self.model = model
         self.graph.finalize()
+
+    def _lower_dag(self):
+        """General graphs: every placeholder the loss depends on is an input, except those that only feed a loss op's
+        label side (or the subtraction of a squared error), which are labels.  The model is a ``GraphModel``."""
+        from .models.graph_model import GraphModel
+        self.dag = True
+        self.lowered = {}
+        order = GraphModel._topological(self.loss_node)
+        label_set = []
+        for n in order:
+            if n.op in ("keras_mse", "softmax_xent", "sparse_softmax_xent") and _match(n.inputs[0], "Placeholder"):
+                label_set.append(n.inputs[0])
+            elif n.op == "sub":
+                label_set += [i for i in n.inputs if _match(i, "Placeholder")]
+        consumers: Dict[int, List[Tensor]] = {}
+        for n in order:
+            for i in n.inputs:
+                if isinstance(i, Tensor):
+                    consumers.setdefault(id(i), []).append(n)
+        labels = [p for p in dict.fromkeys(label_set)
+                  if all(c.op in ("keras_mse", "softmax_xent", "sparse_softmax_xent", "sub") for c in consumers.get(id(p), []))]
+        inputs = [n for n in order if n.op == "Placeholder" and n not in labels and n is not self.graph.learning_phase]
+        if not inputs or not labels:
+            raise NotImplementedError("the loss must depend on at least one input placeholder and one label placeholder")
+        self.input_nodes, self.label_nodes = inputs, labels
+        self.input, self.labels = inputs[0], labels[0]
+        # the output a metric or a fetch of predictions refers to: the non-label operand of the first loss op
+        self.preds = None
+        for n in order:
+            if n.op in ("keras_mse", "softmax_xent", "sparse_softmax_xent"):
+                self.preds = n.inputs[1]
+                break
+        acc = None
+        for n in self.graph.nodes:
+            if self._match_accuracy_dag(n):
+                self.accuracy_nodes.append(n)
+                acc = n
+        model = GraphModel(self.loss_node, inputs, labels, accuracy_node=acc, output_node=self.preds)
+        opt_node = self.train_op.attrs["optimizer"]
+        strategy = self._pick_strategy(opt_node)
+        model.loss = _losses.get("mean_squared_error")         # placeholder entry: the graph computes its own loss
+        pad = strategy.var_alignment() if strategy is not None and hasattr(strategy, "var_alignment") else 64
+        model.build(device=_pick_device(), seed=self.graph.__dict__.get("seed"), pad_multiple=pad)
+        model.optimizer = opt_node.optimizer
+        model.metrics = ["accuracy"] if acc is not None else []
+        if strategy is not None:
+            model.strategy = strategy
+        if not getattr(model.strategy, "owns_optimizer_state", False):
+            model.optimizer.create_slots(model.store)
+        model.strategy.prepare(model)
+        model._extra_categorical = False
+        model._report_binary = False
+        model.matmul_dtype = "fp32"
+        model.compiled = True
+        self.model = model
+        self._chain_input_shape = model.input_shape
+        self.graph.finalize()
+
+    def _match_accuracy_dag(self, node) -> bool:
+        """``reduce_mean(cast(equal(a, b)))`` over anything: evaluated as written."""
+        return _match(node, "reduce_mean") and _match(node.inputs[0], "cast") and _match(node.inputs[0].inputs[0], "equal")
 
     def _lower_chain(self, preds):
         """Walk from the model output back to its input placeholder and turn what is found into layers: Keras layer
@@ -529,6 +599,9 @@ class GraphEngine(ModelEngine):
 
     def graph_def_nodes(self):
         from . import graph_def as gd
+        if self.dag:
+            return [gd.Node(n.name, n.op if n.op != "layer" else type(n.attrs["layer"]).__name__,
+                            [i.name for i in n.inputs if isinstance(i, Tensor)], n.device) for n in self.graph.nodes]
         srv = _cluster.current_server()
         wdev = "/job:worker/task:%d" % srv.task_index if srv is not None and srv.job_name == "worker" else ""
         setter = self.graph.device_setter
@@ -581,6 +654,8 @@ class GraphEngine(ModelEngine):
         feed = {}
         self._env = {}
         self._training = False
+        if self.dag:
+            return self._run_dag(fetch_struct, feed_dict or {})
         for k, v in (feed_dict or {}).items():
             if k is self.input:
                 feed["x"] = v
@@ -599,6 +674,27 @@ class GraphEngine(ModelEngine):
         if "y" in feed:
             feed["y"] = self._env[self.labels] = self._to_device(feed["y"])
         return super().run(fetch_struct, feed)
+
+
+def _run_dag(self, fetch_struct, feed_dict):
+    """``Session.run`` on a general graph: the fed placeholders are bound by identity, in placeholder order."""
+    feed = {}
+    for k, v in feed_dict.items():
+        if k is self.graph.learning_phase:
+            feed["training"] = bool(v)
+            self._training = bool(v)
+        elif isinstance(k, Tensor):
+            self._env[k] = self._to_device(v)
+        else:
+            feed[k] = v
+    if all(p in self._env for p in self.input_nodes):
+        feed["x"] = tuple(self._env[p] for p in self.input_nodes)
+    if all(p in self._env for p in self.label_nodes):
+        feed["y"] = tuple(self._env[p] for p in self.label_nodes)
+    return ModelEngine.run(self, fetch_struct, feed)
+
+
+GraphEngine._run_dag = _run_dag
 
 
 def _pick_device():

@@ -212,6 +212,8 @@ class ModelEngine:
         (it synchronises the stream), so small feeds go through a ring of pinned staging buffers and one asynchronous
         copy each (`FeedStager`); the tensors are consumed inside the same `run`."""
         dev = self.model.device
+        if isinstance(a, (tuple, list)) and a and all(isinstance(t, torch.Tensor) for t in a):
+            return tuple(self._to_device(t) for t in a)      # a model with several fed placeholders
         if dev.type == "cuda" and not isinstance(a, torch.Tensor):
             stager = getattr(self, "_stager", None)
             if stager is None:
@@ -254,7 +256,8 @@ class ModelEngine:
             if need_stats:
                 m.stats.zero_()
             if training:
-                plan = m.fused_step_plan(int(xd.shape[0])) if hasattr(m, "fused_step_plan") else None
+                plan = m.fused_step_plan(int(xd.shape[0])) if hasattr(m, "fused_step_plan") and not isinstance(xd, tuple) \
+                    else None
                 if plan is not None:
                     m.train_steps_fused(xd, yd, int(xd.shape[0]), 1, plan)     # the whole step in one launch
                 else:

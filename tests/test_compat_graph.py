@@ -156,25 +156,132 @@ def test_hand_written_matmul_graph_trains_and_keeps_variable_names(tmp_path):
     tf.reset_default_graph()
 
 
-def test_unsupported_op_on_the_model_path_is_named():
+def _torch_reference(weights, feeds, loss_fn, steps, lr=1e-3):
+    """Plain PyTorch (fp32, autograd, TF-formula Adam) on copies of the model's initial weights."""
+    import torch
+    ws = {k: v.clone().requires_grad_() for k, v in weights.items()}
+    m = {k: torch.zeros_like(v) for k, v in ws.items()}
+    v2 = {k: torch.zeros_like(v) for k, v in ws.items()}
+    losses = []
+    for t in range(1, steps + 1):
+        loss = loss_fn(ws, *feeds)
+        for w in ws.values():
+            w.grad = None
+        loss.backward()
+        losses.append(float(loss.detach()))
+        lr_t = lr * (1 - 0.999 ** t) ** 0.5 / (1 - 0.9 ** t)
+        with torch.no_grad():
+            for k, w in ws.items():
+                m[k].mul_(0.9).add_(w.grad, alpha=0.1)
+                v2[k].mul_(0.999).addcmul_(w.grad, w.grad, value=0.001)
+                w.sub_(lr_t * m[k] / (v2[k].sqrt() + 1e-8))
+    return losses
+
+
+def test_residual_mlp_matches_pytorch_reference(tmp_path):
+    """A skip connection and a non-layer op on the model path: the graph is differentiated as written (reverse mode
+    over the autograd wrappers of the fused kernels) and follows a plain PyTorch implementation step for step."""
+    import torch
+    tf.reset_default_graph()
+    x = tf.placeholder(tf.float32, shape=(None, 16))
+    y = tf.placeholder(tf.float32, shape=(None, 16))
+    h = Dense(16, activation="relu")(x)
+    h2 = Dense(16, activation="relu")(h + x)               # residual add feeding the next layer
+    p = Dense(16, activation="sigmoid")(h2 + h)
+    loss = tf.reduce_mean(keras.losses.mean_squared_error(y, p))
+    acc = tf.reduce_mean(tf.cast(tf.equal(tf.round(p), tf.round(y)), "float"))
+    gs = tf.Variable(0, dtype=tf.int64, name="global_step", trainable=False)
+    train_op = tf.train.AdamOptimizer().minimize(loss, global_step=gs)
+    eng = tf.get_default_graph().engine()
+    assert eng.dag
+    names = [v.name for v in eng.model.store.trainable]
+    assert names == ["dense_1/kernel", "dense_1/bias", "dense_2/kernel", "dense_2/bias", "dense_3/kernel", "dense_3/bias"]
+    w0 = {v.name: v.tensor.clone() for v in eng.model.store.trainable}
+    g = torch.Generator().manual_seed(0)
+    bx = torch.rand(64, 16, generator=g)
+    by = (torch.rand(64, 16, generator=g) > 0.5).float()
+
+    def ref_loss(w, bx, by):
+        h = torch.relu(bx @ w["dense_1/kernel"] + w["dense_1/bias"])
+        h2 = torch.relu((h + bx) @ w["dense_2/kernel"] + w["dense_2/bias"])
+        p = torch.sigmoid((h2 + h) @ w["dense_3/kernel"] + w["dense_3/bias"])
+        return ((p - by) ** 2).mean()
+
+    want = _torch_reference(w0, (bx, by), ref_loss, 40)
+    got = []
+    with tf.train.MonitoredTrainingSession(master="", is_chief=True, checkpoint_dir=str(tmp_path)) as sess:
+        for _ in range(40):
+            l, a, _ = sess.run([loss, acc, train_op], feed_dict={x: bx.numpy(), y: by.numpy(), K.learning_phase(): 1})
+            got.append(l)
+        assert sess.run(gs) == 40
+        val = acc.eval({x: bx.numpy(), y: by.numpy(), K.learning_phase(): 0}, session=sess)
+        assert 0.0 <= val <= 1.0 and abs(val - a) < 0.2
+    assert got[-1] < got[0]
+    assert max(abs(a - b) for a, b in zip(got, want)) < 2e-5, (got[-3:], want[-3:])
+    # sessions, checkpoints and the graph dump work on it as on a chain
+    ck = latest_checkpoint(str(tmp_path))
+    assert ck is not None and ck.endswith("-40")
+    assert {"dense_2/kernel", "dense_2/kernel/Adam_1", "global_step"} <= set(dict(list_variables(ck)))
+    assert os.path.exists(os.path.join(str(tmp_path), "graph.pbtxt"))
+    tf.reset_default_graph()
+
+
+def test_two_inputs_two_summed_losses_match_pytorch_reference():
+    """Two input placeholders, two branches joined by an add, two heads whose losses are added up."""
+    import torch
+    tf.reset_default_graph()
+    xa = tf.placeholder(tf.float32, shape=(None, 12))
+    xb = tf.placeholder(tf.float32, shape=(None, 6))
+    ya = tf.placeholder(tf.float32, shape=(None, 5))        # one-hot classes
+    yb = tf.placeholder(tf.float32, shape=(None, 3))
+    trunk = Dense(24, activation="relu")(xa) + Dense(24, activation="relu")(xb)
+    logits = Dense(5)(trunk)
+    reg = Dense(3, activation="sigmoid")(trunk)
+    loss = tf.reduce_mean(tf.nn.softmax_cross_entropy_with_logits(labels=ya, logits=logits)) \
+        + tf.reduce_mean(keras.losses.mean_squared_error(yb, reg))
+    train_op = tf.train.AdamOptimizer(learning_rate=0.003).minimize(loss)
+    eng = tf.get_default_graph().engine()
+    assert eng.dag and [p.name for p in eng.input_nodes] == [xa.name, xb.name] and len(eng.label_nodes) == 2
+    w0 = {v.name: v.tensor.clone() for v in eng.model.store.trainable}
+    g = torch.Generator().manual_seed(1)
+    a, b = torch.randn(48, 12, generator=g), torch.randn(48, 6, generator=g)
+    cls = torch.nn.functional.one_hot(torch.randint(0, 5, (48,), generator=g), 5).float()
+    r = torch.rand(48, 3, generator=g)
+
+    def ref_loss(w, a, b, cls, r):
+        t = torch.relu(a @ w["dense_1/kernel"] + w["dense_1/bias"]) + torch.relu(b @ w["dense_2/kernel"] + w["dense_2/bias"])
+        lg = t @ w["dense_3/kernel"] + w["dense_3/bias"]
+        rg = torch.sigmoid(t @ w["dense_4/kernel"] + w["dense_4/bias"])
+        return -(cls * torch.log_softmax(lg, dim=1)).sum(dim=1).mean() + ((rg - r) ** 2).mean()
+
+    want = _torch_reference(w0, (a, b, cls, r), ref_loss, 30, lr=0.003)
+    got = []
+    with tf.Session() as sess:
+        for _ in range(30):
+            l, _ = sess.run([loss, train_op], feed_dict={xa: a.numpy(), xb: b.numpy(), ya: cls.numpy(), yb: r.numpy()})
+            got.append(l)
+    assert got[-1] < 0.8 * got[0]
+    assert max(abs(x1 - x2) for x1, x2 in zip(got, want)) < 5e-5, (got[-3:], want[-3:])
+    tf.reset_default_graph()
+
+
+def test_non_layer_op_on_the_model_path():
+    """``tf.square`` applied to a layer's output (neither a layer nor a matmul group) trains through the general path."""
+    import torch
     tf.reset_default_graph()
     x = tf.placeholder(tf.float32, shape=(None, 8))
     y = tf.placeholder(tf.float32, shape=(None, 4))
-    h = Dense(4)(x)
-    p = tf.square(h)                                   # not a layer, matmul group or activation
+    p = tf.square(Dense(4)(x))
     loss = tf.reduce_mean(tf.square(p - y))
-    tf.train.AdamOptimizer().minimize(loss)
-    with pytest.raises(NotImplementedError, match="op 'square'"):
-        tf.get_default_graph().engine()
-    tf.reset_default_graph()
-    # a skip connection: two activations added
-    x = tf.placeholder(tf.float32, shape=(None, 8))
-    y = tf.placeholder(tf.float32, shape=(None, 8))
-    h = Dense(8, activation="relu")(x)
-    loss = tf.reduce_mean(tf.square(tf.nn.relu(h + x) - y))
-    tf.train.AdamOptimizer().minimize(loss)
-    with pytest.raises(NotImplementedError, match="skip connections"):
-        tf.get_default_graph().engine()
+    train_op = tf.train.GradientDescentOptimizer(0.05).minimize(loss)
+    assert tf.get_default_graph().engine().dag
+    g = torch.Generator().manual_seed(2)
+    bx, by = torch.randn(32, 8, generator=g).numpy(), torch.rand(32, 4, generator=g).numpy()
+    with tf.Session() as sess:
+        first = sess.run([loss, train_op], feed_dict={x: bx, y: by})[0]
+        for _ in range(50):
+            last = sess.run([loss, train_op], feed_dict={x: bx, y: by})[0]
+    assert last < 0.7 * first
     tf.reset_default_graph()
 
 
