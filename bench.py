@@ -60,6 +60,9 @@ def parse_args(argv=None):
                          "small-batch replica whose launches would be host-bound; 0 = eager launches)")
     ap.add_argument("--fused", type=int, default=-1,
                     help="one-launch whole-step kernel for the small-batch reference MLP (-1 = when available, 0 = off)")
+    ap.add_argument("--workers", type=int, default=1,
+                    help="asynchronous workers inside the GPU for the one-launch step kernel of the small-batch reference "
+                         "MLP: lock-free updates of shared variables, one shared global_step (the reference's mode)")
     ap.add_argument("--bucket-mb", type=float, default=64.0)
     ap.add_argument("--width", type=int, default=16384, help="wide_mlp hidden width")
     ap.add_argument("--depth", type=int, default=5, help="wide_mlp hidden depth")
@@ -469,7 +472,8 @@ def run_rank(args) -> None:
     if args.fused == 1 and plan is None:
         raise SystemExit("--fused 1: no fused step kernel for this model / batch / world size")
     if plan is not None:
-        pool = max(pool, 128)
+        pool = max(pool, 128 if args.workers <= 1 else 4096)     # mini-batches per launch
+        model.async_workers = max(1, args.workers)
     x_all, y_all = make(B * pool, 1000 + rank)
     batches = [(x_all[i * B:(i + 1) * B], y_all[i * B:(i + 1) * B]) for i in range(pool)]
 
@@ -627,7 +631,9 @@ def run_rank(args) -> None:
     value = global_batch * args.steps / elapsed
     if rank == 0:
         out = {
-            "metric": "examples/sec (whole node) %s MNIST-shape model" % ("sync-DP" if args.mode == "sync" else "async-PS"),
+            "metric": "examples/sec (whole node) %s %s" % (
+                "sync-DP" if args.mode == "sync" else "async-PS",
+                "reference XOR MLP (64-128-128-32)" if args.model == "xor_mlp" else "MNIST-shape model"),
             "value": value,
             "unit": "examples/s",
             "n_gpus": args.gpus,
@@ -639,12 +645,14 @@ def run_rank(args) -> None:
             "vs_baseline": value / BASELINE_EXAMPLES_PER_SEC,
             "dtype": {"fp32": "fp32", "fp32_split": "fp32 (operands as three bf16 limbs, fp32 accumulate, fp32-level accuracy)",
                       "bf16": "bf16 operands / fp32 accumulate (wide dense layers), fp32 elsewhere"}[args.matmul],
-            "data": "synthetic (device-resident MNIST-shaped inputs, random-init weights)",
+            "data": "synthetic (device-resident %s inputs, random-init weights)"
+                    % ("XOR-task" if args.model == "xor_mlp" else "MNIST-shaped"),
             "config": {"model": args.model, "global_batch": global_batch, "batch_per_gpu": B, "seq_len": None,
                        "parallelism": ("dp%d" if args.mode == "sync" else "async-ps%d") % world, "params": model.store.num_params,
                        "optimizer": "adam", "learning_rate": model.optimizer.lr,
                        "compile_seconds": t_compile, "device_initialised": bool(getattr(model.store, "device_initialised", False)),
                        "hip_graph": bool(use_graph), "fused_step_kernel": plan is not None,
+                       "intra_gpu_async_workers": (model.async_workers if plan is not None else None),
                        "allreduce": args.allreduce if (multi and args.mode == "sync") else None, "allreduce_us": exchange_us,
                        "train_loss": logs.get("loss"), "train_acc": logs.get("acc"), "test_acc": test_acc,
                        "eval_steps": n_eval if test_acc is not None else 0,

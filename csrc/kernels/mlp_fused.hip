@@ -21,6 +21,20 @@
 //   * dropout masks are the same counter-based function of (seed, global_step, index) as in the
 //     layer-wise kernels, so both paths draw identical masks; all sums have a fixed order.
 // Variables are read with sc1 (L2-served) loads: the CU re-reads values it stored one step earlier.
+//
+// Asynchronous workers inside one GPU (MULTI instantiation).  The reference's training mode is several workers
+// updating shared variables without locks or barriers, with one shared global_step as the budget
+// (/root/reference/example.py:136-139,168-170,187: plain AdamOptimizer, use_locking=False).  The same semantics
+// on one chip: up to `workers` workgroups, one CU each, run this step loop at once against the SAME variables and
+// Adam slots in HBM/L2.  A step is claimed with one returning atomic add on a ticket word (step number = ticket,
+// mini-batch = ticket, so every mini-batch is consumed exactly once and the launch ends after `nsteps` steps in
+// total); W1 and the biases are re-read from L2 at the start of every step because other workers have written them;
+// updates are plain read-modify-write (a lost update is the reference's own race).  All workers must share one
+// L2 for their sc1 loads to see each other's stores, and the per-XCD L2s are not coherent: the first workgroup
+// to arrive elects its XCD with a compare-and-swap, workgroups on other XCDs leave at once, the first `workers`
+// arrivals on the elected XCD work.  Eight times as many workgroups as workers are launched (they are dealt
+// round-robin over the XCDs); whatever the placement turns out to be, at least the electing workgroup works, so
+// placement decides speed, never the result.
 #include "common.h"
 #include "lds_mma.h"
 
@@ -59,6 +73,9 @@ struct FusedArgs {
     float* beta_powers;  // [2] or null
     float* stats;        // [4] running statistics or null
     long long* prof;     // [16] shader-clock timestamps of the last step's phases, or null (profiling aid)
+    unsigned int* ctl;   // MULTI: {elected XCD (0xFFFFFFFF = none yet), workers admitted, workgroups left, step tickets}
+    int workers;         // MULTI: workgroups that may train at once
+    int stagger;         // MULTI: worker number i starts i * stagger ticks of the 100 MHz wall clock late
 };
 
 // Phase timestamp i of the launch's last step (thread 0 only; a scalar branch when profiling is off).
@@ -137,7 +154,24 @@ __device__ __forceinline__ float opt_update(const Opt& o, float w, float& m, flo
 // pointers per element (half the address registers and address arithmetic of flat accesses).
 struct VarBufs {
     __amdgpu_buffer_rsrc_t w, m, v;
+    float* wptr;          // the variables once more as a plain pointer (atomic adds of the asynchronous workers)
 };
+// Several workers: the step is ADDED to the variable with a hardware float atomic, so concurrent updates of one
+// element all land whatever their timing (a plain read-modify-write would keep one of them: workers that start
+// together run in lockstep and would lose seven updates of eight).  The Adam slots stay plain stores: a lost slot
+// update drops one sample from a running average.
+template <int OPT>
+__device__ __forceinline__ void opt_update_shared(const Opt& o, float* wptr, int byte_off, float& m, float& v, float g) {
+    float step;
+    if (OPT == 0) {
+        m = o.b1 * m + (1.0f - o.b1) * g;
+        v = o.b2 * v + (1.0f - o.b2) * g * g;
+        step = o.lr_t * m * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) + o.eps);
+    } else {
+        step = o.lr * g;
+    }
+    unsafeAtomicAdd(wptr + (byte_off >> 2), -step);
+}
 __device__ __forceinline__ float vb_load(__amdgpu_buffer_rsrc_t r, int byte_off) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 16));   // sc1: L2-served
 }
@@ -164,6 +198,7 @@ struct TileState {
         }
     }
     // apply the gradient tile; `mirror` (optional) receives the new values as an LDS image [rows][ldm]
+    template <bool SHARED = false>
     __device__ __forceinline__ void finish(const VarBufs& vb, const Opt& o, const f32x16& g, long long off, int N, int i0,
                                            int n0, int lane, float* mirror, int ldm) {
         const int li = lane & 31, h = lane >> 5;
@@ -172,6 +207,14 @@ struct TileState {
         for (int r = 0; r < 16; ++r) {
             const int rr = (r & 3) + 8 * (r >> 2);
             const int bo = base + rr * N * 4;
+            if (SHARED) {
+                opt_update_shared<OPT>(o, vb.wptr, bo, m[r], v[r], g[r]);
+                if (OPT == 0) {
+                    vb_store(vb.m, bo, m[r]);
+                    vb_store(vb.v, bo, v[r]);
+                }
+                continue;
+            }
             const float nw = opt_update<OPT>(o, w[r], m[r], v[r], g[r]);
             vb_store(vb.w, bo, nw);
             if (OPT == 0) {
@@ -199,6 +242,7 @@ struct BiasState {
         }
     }
     // `mirror`: LDS copy of the bias that the next step's forward epilogue reads
+    template <bool SHARED = false>
     __device__ __forceinline__ void finish(const VarBufs& vb, const Opt& o, const float* dz, int ld, long long off, int N,
                                            int tid, float* mirror) {
         if (tid < N) {
@@ -211,6 +255,14 @@ struct BiasState {
                 s3 += dz[(r + 3) * ld + tid];
             }
             const int bo = ((int)off + tid) * 4;
+            if (SHARED) {
+                opt_update_shared<OPT>(o, vb.wptr, bo, m, v, (s0 + s1) + (s2 + s3));
+                if (OPT == 0) {
+                    vb_store(vb.m, bo, m);
+                    vb_store(vb.v, bo, v);
+                }
+                return;
+            }
             const float nw = opt_update<OPT>(o, w, m, v, (s0 + s1) + (s2 + s3));
             vb_store(vb.w, bo, nw);
             if (OPT == 0) {
@@ -222,7 +274,7 @@ struct BiasState {
     }
 };
 
-template <int OPT>
+template <int OPT, bool MULTI>
 __global__ __launch_bounds__(NT, 1) void mlp3_fused_kernel(const FusedArgs p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* sX = lds;
@@ -240,6 +292,33 @@ __global__ __launch_bounds__(NT, 1) void mlp3_fused_kernel(const FusedArgs p) {
     int tid = tid0;
     const int B = p.B;
     const long long step0 = *p.step_ptr;
+    int* sTicket = reinterpret_cast<int*>(sRed) + 24;      // [0] this step's ticket, [1] the next one
+    bool worker = true;
+    if (MULTI) {
+        // elect an XCD, admit the first `workers` workgroups that run on it, hand the first ticket to each of them
+        if (tid0 == 0) {
+            const unsigned int xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 0xFu;   // HW_REG_XCC_ID[3:0]
+            const unsigned int seen = atomicCAS(p.ctl + 0, 0xFFFFFFFFu, xcc);
+            int ticket = -1;
+            if (seen == 0xFFFFFFFFu || seen == xcc) {
+                const unsigned int slot = atomicAdd(p.ctl + 1, 1u);
+                if (slot < (unsigned)p.workers) {
+                    // Workers that start together stay in lockstep (same code, same step time): all would compute
+                    // their gradients from the same variables and apply them at once - one step of k times the
+                    // batch and k times the rate.  Spread over the step period, every worker reads variables that
+                    // already hold the others' latest updates: delayed-gradient SGD at the nominal rate.
+                    const unsigned long long until = wall_clock64() + (unsigned long long)slot * (unsigned)p.stagger;
+                    while (wall_clock64() < until) __builtin_amdgcn_s_sleep(8);
+                    ticket = (int)atomicAdd(p.ctl + 3, 1u);
+                }
+            }
+            sTicket[0] = (ticket >= 0 && ticket < p.nsteps) ? ticket : -1;
+        }
+        __syncthreads();
+        worker = sTicket[0] >= 0;
+    }
+    const int ticket = MULTI ? sTicket[0] : 0;
+    int steps_done = 0;
     float loss_acc = 0.f, acc_acc = 0.f, cat_acc = 0.f;
     float b1_pow = 1.f, b2_pow = 1.f;
     const bool drop1 = p.training && p.keep1 < 1.0f, drop2 = p.training && p.keep2 < 1.0f;
@@ -249,6 +328,7 @@ __global__ __launch_bounds__(NT, 1) void mlp3_fused_kernel(const FusedArgs p) {
     vb.w = __builtin_amdgcn_make_buffer_rsrc(p.params, 0, (int)W_BYTES, 0x00020000);
     vb.m = __builtin_amdgcn_make_buffer_rsrc(OPT == 0 ? p.slot_m : p.params, 0, (int)W_BYTES, 0x00020000);
     vb.v = __builtin_amdgcn_make_buffer_rsrc(OPT == 0 ? p.slot_v : p.params, 0, (int)W_BYTES, 0x00020000);
+    vb.wptr = p.params;
 
     Stage<64, 128> pw;             // W1, a 64-row chunk of W2 (forward)
     Stage<128, 64> pt;             // a 64-column slice of W2 (dgrad)
@@ -256,15 +336,16 @@ __global__ __launch_bounds__(NT, 1) void mlp3_fused_kernel(const FusedArgs p) {
     Stage<BM, D0> px;              // next batch
     Stage<BM, D3> py;
 
-    px.template issue<false>(p.X, (unsigned)B * D0 * 4, D0, tid);
-    py.template issue<false>(p.Y, (unsigned)B * D3 * 4, D3, tid);
+    if (worker) {
+    px.template issue<false>(p.X + (long long)ticket * B * D0, (unsigned)B * D0 * 4, D0, tid);
+    py.template issue<false>(p.Y + (long long)ticket * B * D3, (unsigned)B * D3 * 4, D3, tid);
     pw.template issue<true>(p.params + p.off[0], W_BYTES, D1, tid);
-    pw.commit(sW, tid);            // W1 image; later steps find it already there
+    pw.commit(sW, tid);            // W1 image; later steps of a lone worker find it already there
     if (tid < D1) sB1[tid] = ld1_sc1(p.params + p.off[1] + tid);
     if (tid < D2) sB2[tid] = ld1_sc1(p.params + p.off[3] + tid);
     if (tid < D3) sB3[tid] = ld1_sc1(p.params + p.off[5] + tid);
 
-    for (int s = 0; s < p.nsteps; ++s) {
+    for (int s = MULTI ? ticket : 0; s >= 0 && s < p.nsteps;) {
         // The thread index is made opaque once per step: every address and dropout-hash term below is step-invariant,
         // and hoisting them all out of this loop would cost far more registers than recomputing them.
         asm volatile("" : "+v"(tid));
@@ -276,8 +357,8 @@ __global__ __launch_bounds__(NT, 1) void mlp3_fused_kernel(const FusedArgs p) {
         DTF_PROF(0);
         Opt o;
         o.lr = p.lr; o.b1 = p.beta1; o.b2 = p.beta2; o.eps = p.eps;
-        if ((s & 63) == 0) {           // beta^t as running products, re-based every 64 steps: powf costs hundreds of
-            b1_pow = powf(p.beta1, (float)step);    // instructions
+        if (MULTI || (s & 63) == 0) {  // beta^t as running products, re-based every 64 steps: powf costs hundreds of
+            b1_pow = powf(p.beta1, (float)step);    // instructions (a worker among several takes steps out of sequence)
             b2_pow = powf(p.beta2, (float)step);
         }
         b1_pow *= p.beta1;
@@ -382,6 +463,7 @@ __global__ __launch_bounds__(NT, 1) void mlp3_fused_kernel(const FusedArgs p) {
                 sP[row * L3 + c] = dz;
             }
         }
+        if (MULTI && tid == 0) sTicket[1] = (int)atomicAdd(p.ctl + 3, 1u);     // the step this worker takes next
         __syncthreads();
         DTF_PROF(6);
 
@@ -413,8 +495,8 @@ __global__ __launch_bounds__(NT, 1) void mlp3_fused_kernel(const FusedArgs p) {
         //      Waves 0..3 first apply W3 / b3 (VALU + memory) while their SIMD partners 4..7 already run MFMAs.
         pt.commit(sW, tid);
         pt.template issue<true>(p.params + p.off[2] + 64, W_BYTES, D2, tid);            // W2 columns 64..127
-        if (wave < 4) ts.finish(vb, o, g3, p.off[4], D3, wave * 32, 0, lane, nullptr, 0);
-        bs3.finish(vb, o, sP, L3, p.off[5], D3, tid, sB3);
+        if (wave < 4) ts.template finish<MULTI>(vb, o, g3, p.off[4], D3, wave * 32, 0, lane, nullptr, 0);
+        bs3.template finish<MULTI>(vb, o, sP, L3, p.off[5], D3, tid, sB3);
         f32x16 g2[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -422,7 +504,7 @@ __global__ __launch_bounds__(NT, 1) void mlp3_fused_kernel(const FusedArgs p) {
             const int t = wave + 8 * q;
             tile_mma<false, false, BM>(g2[q], sH1, L1, (t >> 2) * 32, sH2, L2, (t & 3) * 32, lane);
         }
-        bs2.finish(vb, o, sH2, L2, p.off[3], D2, tid, sB2);
+        bs2.template finish<MULTI>(vb, o, sH2, L2, p.off[3], D2, tid, sB2);
         __syncthreads();                                                                // h1 readers done; slice 0 visible
         DTF_PROF(9);
         // ---- dz1 = (dz2 W2^T) * (h1 > 0) / keep1 in place of h1, summed over two 64-wide slices of W2's columns
@@ -445,9 +527,10 @@ __global__ __launch_bounds__(NT, 1) void mlp3_fused_kernel(const FusedArgs p) {
         // ---- apply W2 from the held accumulators, and dW1 = x^T dz1 applied directly (input block tm, output block
         //      tn; new W1 mirrored into its LDS image).  The two waves of a SIMD take the two jobs in opposite order,
         //      so one's update arithmetic and memory traffic overlap the other's MFMAs.
-        if (s + 1 < p.nsteps) {
-            px.template issue<false>(p.X + (long long)(s + 1) * B * D0, (unsigned)B * D0 * 4, D0, tid);
-            py.template issue<false>(p.Y + (long long)(s + 1) * B * D3, (unsigned)B * D3 * 4, D3, tid);
+        const int next = MULTI ? sTicket[1] : s + 1;       // (written several barriers ago)
+        if (next < p.nsteps) {
+            px.template issue<false>(p.X + (long long)next * B * D0, (unsigned)B * D0 * 4, D0, tid);
+            py.template issue<false>(p.Y + (long long)next * B * D3, (unsigned)B * D3 * 4, D3, tid);
         }
         {
             const int i2a = (wave >> 2) * 32, i2b = ((wave + 8) >> 2) * 32, n2 = (wave & 3) * 32;
@@ -455,34 +538,50 @@ __global__ __launch_bounds__(NT, 1) void mlp3_fused_kernel(const FusedArgs p) {
             if (wave < 4) {
                 t2.issue(vb, p.off[2], D2, i2a, n2, lane);
                 t1.issue(vb, p.off[0], D1, tm * 32, tn * 32, lane);
-                t2.finish(vb, o, g2[0], p.off[2], D2, i2a, n2, lane, nullptr, 0);
+                t2.template finish<MULTI>(vb, o, g2[0], p.off[2], D2, i2a, n2, lane, nullptr, 0);
                 t2.issue(vb, p.off[2], D2, i2b, n2, lane);
                 f32x16 acc; zero(acc);
                 tile_mma<false, false, BM>(acc, sX, LX, tm * 32, sH1, L1, tn * 32, lane);
-                t2.finish(vb, o, g2[1], p.off[2], D2, i2b, n2, lane, nullptr, 0);
-                t1.finish(vb, o, acc, p.off[0], D1, tm * 32, tn * 32, lane, sW, L1);
+                t2.template finish<MULTI>(vb, o, g2[1], p.off[2], D2, i2b, n2, lane, nullptr, 0);
+                t1.template finish<MULTI>(vb, o, acc, p.off[0], D1, tm * 32, tn * 32, lane, sW, L1);
             } else {
                 t1.issue(vb, p.off[0], D1, tm * 32, tn * 32, lane);
                 t2.issue(vb, p.off[2], D2, i2a, n2, lane);
                 f32x16 acc; zero(acc);
                 tile_mma<false, false, BM>(acc, sX, LX, tm * 32, sH1, L1, tn * 32, lane);
-                t2.finish(vb, o, g2[0], p.off[2], D2, i2a, n2, lane, nullptr, 0);
+                t2.template finish<MULTI>(vb, o, g2[0], p.off[2], D2, i2a, n2, lane, nullptr, 0);
                 t2.issue(vb, p.off[2], D2, i2b, n2, lane);
-                t1.finish(vb, o, acc, p.off[0], D1, tm * 32, tn * 32, lane, sW, L1);
-                t2.finish(vb, o, g2[1], p.off[2], D2, i2b, n2, lane, nullptr, 0);
+                t1.template finish<MULTI>(vb, o, acc, p.off[0], D1, tm * 32, tn * 32, lane, sW, L1);
+                t2.template finish<MULTI>(vb, o, g2[1], p.off[2], D2, i2b, n2, lane, nullptr, 0);
             }
         }
         DTF_PROF(11);
-        bs1.finish(vb, o, sH1, L1, p.off[1], D1, tid, sB1);
+        bs1.template finish<MULTI>(vb, o, sH1, L1, p.off[1], D1, tid, sB1);
         // every wave's variable stores must have reached L2 before the next step requests them again
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         DTF_PROF(12);
+        ++steps_done;
+        if (MULTI) {
+            // other workers have updated the variables meanwhile: W1 and the biases come from L2 again (the other
+            // weights are streamed every step anyway); the barrier at the top of the next step publishes the images
+            if (next < p.nsteps) {
+                pw.template issue<true>(p.params + p.off[0], W_BYTES, D1, tid);
+                pw.commit(sW, tid);
+                if (tid < D1) sB1[tid] = ld1_sc1(p.params + p.off[1] + tid);
+                if (tid < D2) sB2[tid] = ld1_sc1(p.params + p.off[3] + tid);
+                if (tid < D3) sB3[tid] = ld1_sc1(p.params + p.off[5] + tid);
+            }
+            s = next;
+        } else {
+            ++s;
+        }
     }
+    }   // worker
 
     // ---- once per launch: statistics, global_step, beta powers
     const int lane = tid0 & 63, wave = tid0 >> 6;
-    if (p.stats) {
+    if (p.stats && worker) {
         const float l = dtf_wave_sum(loss_acc), a = dtf_wave_sum(acc_acc), c = dtf_wave_sum(cat_acc);
         if (lane == 0) { sRed[wave] = l; sRed[8 + wave] = a; sRed[16 + wave] = c; }
         __syncthreads();
@@ -492,11 +591,27 @@ __global__ __launch_bounds__(NT, 1) void mlp3_fused_kernel(const FusedArgs p) {
             const float inv = 1.0f / (float)D3;
             atomicAdd(p.stats + 0, sl * inv);
             atomicAdd(p.stats + 1, sa * inv);
-            atomicAdd(p.stats + 2, (float)B * (float)p.nsteps);
+            atomicAdd(p.stats + 2, (float)B * (float)steps_done);
             if (p.want_cat) atomicAdd(p.stats + 3, sc);
         }
     }
-    if (tid0 == 0) {
+    bool last = true;
+    if (MULTI) {
+        // the workgroup that leaves last (every worker has finished its steps by then) closes the launch and re-arms
+        // the control words for the next one
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid0 == 0) {
+            last = atomicAdd(p.ctl + 2, 1u) == gridDim.x - 1;
+            if (last) {
+                __hip_atomic_store(p.ctl + 0, 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(p.ctl + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(p.ctl + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(p.ctl + 3, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    if (tid0 == 0 && last) {
         *p.step_ptr = step0 + p.nsteps;
         if (p.beta_powers && OPT == 0) {
             p.beta_powers[0] *= powf(p.beta1, (float)p.nsteps);
@@ -523,6 +638,61 @@ DTF_API int dtf_mlp3_fused_supported(int d0, int d1, int d2, int d3, int B) {
 
 // nsteps full training steps (relu, relu, sigmoid; MSE; Adam when opt == 0, SGD when opt == 1) on consecutive
 // mini-batches X[k*B:(k+1)*B], Y[k*B:(k+1)*B].
+namespace {
+int launch_fused(FusedArgs a, int opt, hipStream_t stream) {
+    constexpr size_t lds = sizeof(float) * LDS_FLOATS;
+    static bool once = false;
+    if (!once) {
+        const void* fns[4] = {reinterpret_cast<const void*>(mlp3_fused_kernel<0, false>),
+                              reinterpret_cast<const void*>(mlp3_fused_kernel<1, false>),
+                              reinterpret_cast<const void*>(mlp3_fused_kernel<0, true>),
+                              reinterpret_cast<const void*>(mlp3_fused_kernel<1, true>)};
+        for (const void* f : fns) {
+            const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+        }
+        once = true;
+    }
+    if (a.workers > 1) {
+        // eight workgroups per worker: dealt round-robin over the eight XCDs, about `workers` of them land on the XCD
+        // that gets elected (the others leave at once)
+        const dim3 grid((unsigned)(8 * a.workers));
+        if (opt == 0) hipLaunchKernelGGL((mlp3_fused_kernel<0, true>), grid, dim3(NT), lds, stream, a);
+        else hipLaunchKernelGGL((mlp3_fused_kernel<1, true>), grid, dim3(NT), lds, stream, a);
+    } else {
+        if (opt == 0) hipLaunchKernelGGL((mlp3_fused_kernel<0, false>), dim3(1), dim3(NT), lds, stream, a);
+        else hipLaunchKernelGGL((mlp3_fused_kernel<1, false>), dim3(1), dim3(NT), lds, stream, a);
+    }
+    DTF_CHECK_LAUNCH();
+    return 0;
+}
+}  // namespace
+
+// The same with up to `workers` asynchronous workers (workgroups) sharing the variables, lock-free; `ctl` is a device
+// array of four 32-bit words initialised to {0xFFFFFFFF, 0, 0, 0} that every launch leaves in that state.
+DTF_API int dtf_mlp3_fused_train_async(const float* X, const float* Y, float* params, float* slot_m, float* slot_v,
+                                       const long long* offsets6, int d0, int d1, int d2, int d3, int B, int nsteps,
+                                       int training, int opt, int want_cat, float keep1, float keep2, uint32_t seed1,
+                                       uint32_t seed2, float lr, float beta1, float beta2, float eps, long long* step_ptr,
+                                       float* beta_powers, float* stats, unsigned int* ctl, int workers,
+                                       hipStream_t stream) {
+    if (!dtf_mlp3_fused_supported(d0, d1, d2, d3, B)) return -4;
+    if (opt == 0 && (!slot_m || !slot_v)) return -5;
+    if (opt != 0 && opt != 1) return -6;
+    if (workers < 1 || workers > 32 || (workers > 1 && !ctl)) return -7;
+    if (nsteps <= 0) return 0;
+    FusedArgs a = {};
+    a.X = X; a.Y = Y; a.params = params; a.slot_m = slot_m; a.slot_v = slot_v;
+    for (int i = 0; i < 6; ++i) a.off[i] = offsets6[i];
+    a.B = B; a.nsteps = nsteps; a.training = training; a.want_cat = want_cat;
+    a.keep1 = keep1; a.keep2 = keep2; a.seed1 = seed1; a.seed2 = seed2;
+    a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
+    a.step_ptr = step_ptr; a.beta_powers = beta_powers; a.stats = stats; a.prof = workers > 1 ? nullptr : g_prof_buffer;
+    a.ctl = ctl; a.workers = workers;
+    a.stagger = 3700 / workers;      // a step takes ~37 us = 3700 ticks: the workers' phases tile one step period
+    return launch_fused(a, opt, stream);
+}
+
 DTF_API int dtf_mlp3_fused_train(const float* X, const float* Y, float* params, float* slot_m, float* slot_v,
                                  const long long* offsets6, int d0, int d1, int d2, int d3, int B, int nsteps,
                                  int training, int opt, int want_cat, float keep1, float keep2, uint32_t seed1,
@@ -539,19 +709,6 @@ DTF_API int dtf_mlp3_fused_train(const float* X, const float* Y, float* params, 
     a.keep1 = keep1; a.keep2 = keep2; a.seed1 = seed1; a.seed2 = seed2;
     a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
     a.step_ptr = step_ptr; a.beta_powers = beta_powers; a.stats = stats; a.prof = g_prof_buffer;
-    constexpr size_t lds = sizeof(float) * LDS_FLOATS;
-    static bool once = false;
-    if (!once) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp3_fused_kernel<0>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp3_fused_kernel<1>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        once = true;
-    }
-    if (opt == 0) hipLaunchKernelGGL(mlp3_fused_kernel<0>, dim3(1), dim3(NT), lds, stream, a);
-    else hipLaunchKernelGGL(mlp3_fused_kernel<1>, dim3(1), dim3(NT), lds, stream, a);
-    DTF_CHECK_LAUNCH();
-    return 0;
+    a.ctl = nullptr; a.workers = 1;
+    return launch_fused(a, opt, stream);
 }

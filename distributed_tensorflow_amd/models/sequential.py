@@ -84,6 +84,7 @@ class Sequential:
         self._tail_plan = False       # False = not looked at yet
         self.use_tail_kernel = True   # set False to force the layer-by-layer kernels through the network's tail
         self._after_layer_backward = None   # strategy hook: called as each layer's gradients become final
+        self.async_workers = 1        # asynchronous workers inside the GPU for the one-launch step kernel
         for layer in layers or []:
             self.add(layer)
 
@@ -468,8 +469,11 @@ class Sequential:
         offsets = [x.offset for l in eff for x in (l.kernel, l.bias)]
         return dict(dims=dims, offsets=offsets, opt=kind, m=m, v=v, l1=eff[0], l2=eff[1])
 
-    def train_steps_fused(self, x_buf: torch.Tensor, y_buf: torch.Tensor, batch_size: int, nsteps: int, plan=None):
-        """``nsteps`` training steps on ``x_buf[k*B:(k+1)*B]`` in a single kernel launch."""
+    def train_steps_fused(self, x_buf: torch.Tensor, y_buf: torch.Tensor, batch_size: int, nsteps: int, plan=None,
+                          workers: Optional[int] = None):
+        """``nsteps`` training steps on ``x_buf[k*B:(k+1)*B]`` in a single kernel launch.  ``workers`` (default:
+        ``self.async_workers``, 1): that many asynchronous workers inside the GPU share the variables lock-free and
+        take the steps between them (the reference's training mode, /root/reference/example.py:168-170)."""
         plan = plan or self.fused_step_plan(batch_size)
         if plan is None:
             raise RuntimeError("this model / batch size has no fused step kernel")
@@ -478,7 +482,9 @@ class Sequential:
         # hyper-parameters, keep probabilities and dropout seeds are read at call time, like the layer-wise path does
         F.mlp3_fused_train(x_buf, y_buf, st.flat, plan["m"], plan["v"], plan["offsets"], plan["dims"], batch_size,
                            nsteps, True, plan["opt"], self._extra_categorical, l1.fused_keep, l2.fused_keep,
-                           l1.seed, l2.seed, *hp, st.global_step, st.beta_powers, self.stats)
+                           l1.seed, l2.seed, *hp, st.global_step, st.beta_powers, self.stats,
+                           workers=max(1, min(int(workers if workers is not None else getattr(self, "async_workers", 1)),
+                                              int(nsteps))))
         self._host_step += nsteps
 
     def _snapshot(self):
@@ -498,7 +504,8 @@ class Sequential:
     # ------------------------------------------------------------------ fit
     def fit(self, x, y, epochs: int = 1, batch_size: int = 32, validation_data=None, callbacks=None,
             shuffle: bool = True, verbose: int = 1, steps_per_graph: int = 0, initial_epoch: int = 0,
-            fused: Optional[bool] = None, stream_from_host: bool = False, shuffle_seed: int = 0):
+            fused: Optional[bool] = None, stream_from_host: bool = False, shuffle_seed: int = 0,
+            async_workers: Optional[int] = None):
         """Keras ``fit``.  Data is moved to the device once; each epoch reshuffles on the device.
 
         ``stream_from_host=True`` keeps ``x`` / ``y`` in host memory instead (data sets larger than HBM): C++ worker
@@ -508,8 +515,12 @@ class Sequential:
         ``steps_per_graph > 0`` (GPU only) replays that many consecutive steps from one
         captured hipGraph; 0 launches every kernel eagerly.  ``fused`` (default: automatic) selects the
         one-launch whole-step kernel when the model has one (``fused_step_plan``); ``False`` forces the
-        layer-by-layer path.
+        layer-by-layer path.  ``async_workers=k`` (with that kernel): ``k`` asynchronous workers inside the GPU train
+        on the shared variables lock-free and take an epoch's steps between them, as the reference's worker processes
+        do against its parameter servers (/root/reference/example.py:168-170); ``global_step`` counts every step once.
         """
+        if async_workers is not None:
+            self.async_workers = max(1, int(async_workers))
         self._check_compiled()
         if stream_from_host:
             return self._fit_streamed(x, y, epochs, batch_size, validation_data, callbacks, shuffle, verbose,

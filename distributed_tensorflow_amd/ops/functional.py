@@ -475,11 +475,27 @@ def mlp3_fused_supported(dims, batch: int) -> bool:
     return hasattr(lib, "dtf_mlp3_fused_supported") and bool(lib.dtf_mlp3_fused_supported(*map(int, dims), int(batch)))
 
 
+_fused_ctl = {}
+
+
+def _fused_control_words(device) -> torch.Tensor:
+    """The four control words of the asynchronous-workers launch ({elected XCD, admitted, left, tickets}); every
+    launch leaves them as it found them."""
+    key = (device.type, device.index)
+    if key not in _fused_ctl:
+        _fused_ctl[key] = torch.tensor([-1, 0, 0, 0], dtype=torch.int32, device=device)
+    return _fused_ctl[key]
+
+
 def mlp3_fused_train(x, y, params, slot_m, slot_v, offsets, dims, batch, nsteps, training, opt, want_cat, keep1, keep2,
-                     seed1, seed2, lr, beta1, beta2, eps, step, beta_powers, stats):
+                     seed1, seed2, lr, beta1, beta2, eps, step, beta_powers, stats, workers: int = 1):
     """``nsteps`` complete training steps (forward, MSE, backward, Adam/SGD update) of the reference MLP in ONE
     launch on mini-batches ``x[k*batch:(k+1)*batch]``; GPU only.  ``offsets``: element offsets of
-    W1, b1, W2, b2, W3, b3 inside ``params`` (and the slot buffers)."""
+    W1, b1, W2, b2, W3, b3 inside ``params`` (and the slot buffers).
+
+    ``workers > 1``: that many asynchronous workers (one compute unit each) take the ``nsteps`` steps between them,
+    updating the shared variables without locks - the reference's parameter-server semantics
+    (/root/reference/example.py:168-170) inside one GPU; ``global_step`` still advances by exactly ``nsteps``."""
     import ctypes as C
     nv.require_f32_contig(x, y, params, slot_m, slot_v)
     if not x.is_cuda:
@@ -495,6 +511,17 @@ def mlp3_fused_train(x, y, params, slot_m, slot_v, offsets, dims, batch, nsteps,
     if any(o % 4 for o in offsets):
         raise ValueError("fused step: variable offsets must be multiples of 4 elements")
     offs = (C.c_longlong * 6)(*[int(o) for o in offsets])
+    if int(workers) > 1:
+        fn = nv.declare(nv.kernels(), "dtf_mlp3_fused_train_async",
+                        [nv.c_p] * 6 + [nv.c_i] * 9 + [nv.c_f, nv.c_f, nv.c_u32, nv.c_u32] + [nv.c_f] * 4 + [nv.c_p] * 4
+                        + [nv.c_i, nv.c_p])
+        rc = fn(nv.ptr(x), nv.ptr(y), nv.ptr(params), nv.ptr(slot_m), nv.ptr(slot_v), C.cast(offs, C.c_void_p),
+                int(dims[0]), int(dims[1]), int(dims[2]), int(dims[3]), int(batch), int(nsteps), int(bool(training)),
+                int(opt), int(bool(want_cat)), float(keep1), float(keep2), int(seed1) & _M32, int(seed2) & _M32, float(lr),
+                float(beta1), float(beta2), float(eps), nv.ptr(step), nv.ptr(beta_powers), nv.ptr(stats),
+                nv.ptr(_fused_control_words(x.device)), int(workers), nv.stream_ptr())
+        nv.check(rc, "dtf_mlp3_fused_train_async")
+        return
     rc = nv.kernels().dtf_mlp3_fused_train(
         nv.ptr(x), nv.ptr(y), nv.ptr(params), nv.ptr(slot_m), nv.ptr(slot_v), C.cast(offs, C.c_void_p),
         int(dims[0]), int(dims[1]), int(dims[2]), int(dims[3]), int(batch), int(nsteps), int(bool(training)), int(opt),

@@ -100,3 +100,34 @@ def test_fused_no_dropout_and_tiny_batch(gpu_device):
     b.train_steps_fused(xt, yt, 8, 8)
     torch.testing.assert_close(a.store.flat, b.store.flat, rtol=2e-4, atol=2e-6)
     assert a.global_step == b.global_step == 8
+
+
+def test_async_workers_inside_the_gpu_share_the_variables(gpu_device):
+    """Four asynchronous workers (one compute unit each) take the steps of a launch between them, lock-free on the
+    shared variables - the reference's training mode.  Checked: ``global_step`` advances by exactly the number of
+    steps, every mini-batch is consumed once, the control words are re-armed, training reaches the accuracy of the
+    single-worker run (the races make runs differ in the last digits, not in quality)."""
+    import distributed_tensorflow_amd.ops.functional as Fn
+    from distributed_tensorflow_amd.data import get_data
+    from distributed_tensorflow_amd.models import xor_mlp
+    xt, yt, xv, yv = get_data(30000, seed=3, device=gpu_device)
+    accs = {}
+    for workers in (1, 4):
+        m = xor_mlp()
+        m.compile(loss="mean_squared_error", optimizer="adam", metrics=["binary_rounded_accuracy"], device=gpu_device, seed=1)
+        plan = m.fused_step_plan(50)
+        assert plan is not None
+        for _ in range(6):                               # 6 x 600 steps
+            m.stats.zero_()
+            m.train_steps_fused(xt, yt, 50, 600, plan, workers=workers)
+            seen = m.stats[2].item()
+            assert seen == 50 * 600                      # every mini-batch exactly once
+        assert m.global_step == 3600
+        accs[workers] = m.evaluate(xv, yv, batch_size=1000)[1]
+        if workers > 1:
+            assert Fn._fused_control_words(gpu_device).tolist() == [-1, 0, 0, 0]
+    assert accs[1] > 0.8 and accs[4] > accs[1] - 0.06, accs
+    # a launch with fewer steps than workers, and one step: nobody takes a step twice
+    m.stats.zero_()
+    m.train_steps_fused(xt, yt, 50, 3, plan, workers=8)
+    assert m.global_step == 3603 and m.stats[2].item() == 150
