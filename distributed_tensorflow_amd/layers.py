@@ -425,8 +425,8 @@ class Conv2D(Layer):
             ypool = pool._buf.get("y", shape, x.device)
             arg = pool._arg_buffer(shape, x.device)
             kh, kw = self.kernel_size
-            xin = self._fused_input(x)
-            F.conv_pool_forward(xin, self.kernel.tensor.view(-1, Fo), bias, self.act, kh, kw, "valid", ypool, arg)
+            xin, self._fused_padding = self._fused_input(x)
+            F.conv_pool_forward(xin, self.kernel.tensor.view(-1, Fo), bias, self.act, kh, kw, self._fused_padding, ypool, arg)
             self._x, self._cols, self._y = xin, None, ypool
             pool._x, pool._arg = None, arg
             return ypool
@@ -482,15 +482,18 @@ class Conv2D(Layer):
                                           self.fused_pool.pool_size))
 
     def _fused_input(self, x):
-        """The fused kernels run a VALID convolution: 'same' padding is materialised once per step (a few MB for a
-        first layer), which frees every tap of both kernels from bounds tests."""
-        _, H, W, C = x.shape
+        """(input, padding mode) for the fused kernels.  Their staged form copies whole images into LDS and pads there,
+        so it reads the input as stored; the direct form runs a VALID convolution on a copy padded once per step (a few
+        MB for a first layer), which frees every tap from bounds tests."""
+        B, H, W, C = x.shape
         kh, kw = self.kernel_size
-        _, _, pt, pl, pb, pr = F.conv_geometry(H, W, kh, kw, self.strides, self.padding)
+        OH, OW, pt, pl, pb, pr = F.conv_geometry(H, W, kh, kw, self.strides, self.padding)
         if pt == pl == pb == pr == 0:
-            return x
-        xpad = self._buf.get("xpad_fused", (x.shape[0], H + pt + pb, W + pl + pr, C), x.device)
-        return F.conv_pad(x, pt, pl, H + pt + pb, W + pl + pr, out=xpad)
+            return x, "valid"
+        if F.conv_pool_staged_fits(B, H, W, C, kh, kw, pt, pl, OH // 2, OW // 2, self.filters):
+            return x, self.padding
+        xpad = self._buf.get("xpad_fused", (B, H + pt + pb, W + pl + pr, C), x.device)
+        return F.conv_pad(x, pt, pl, H + pt + pb, W + pl + pr, out=xpad), "valid"
 
     def _backward_fused_pool(self, dpool):
         x, ypool = self._x, self._y
@@ -500,7 +503,8 @@ class Conv2D(Layer):
         if self._ws is None or self._ws[1].numel() < need:
             self._ws = (0, torch.empty(need, dtype=torch.float32, device=x.device))
         F.conv_pool_wgrad(x, dpool.contiguous(), ypool, self.fused_pool._arg, self.kernel.grad.view(-1, Fo),
-                          self.bias.grad if self.bias is not None else None, self.act, kh, kw, "valid", self._ws[1])
+                          self.bias.grad if self.bias is not None else None, self.act, kh, kw, self._fused_padding,
+                          self._ws[1])
         return None
 
     def backward(self, dy):

@@ -82,6 +82,8 @@ def kernels():
         "dtf_maxpool_fwd": [c_p, c_p, c_p] + [c_i] * 6 + [c_p],
         "dtf_conv_pool_supported": [c_i] * 4,
         "dtf_conv_pool_workspace_floats": [c_i] * 4,
+        "dtf_conv_pool_set_staged": [c_i],
+        "dtf_conv_pool_staged_fits": [c_i] * 11,
         "dtf_conv_pool_fwd": [c_p] * 5 + [c_i] * 12 + [c_p],
         "dtf_conv_pool_wgrad": [c_p] * 6 + [c_i] * 12 + [c_p, c_p],
         "dtf_maxpool_bwd": [c_p, c_p, c_p, c_p] + [c_i] * 7 + [c_p],

@@ -620,6 +620,25 @@ def conv_pool_supported(x_shape, KH, KW, filters, strides=(1, 1), padding="valid
     return bool(nv.kernels().dtf_conv_pool_supported(C, KH, KW, filters))
 
 
+_conv_pool_env_read = False
+
+
+def conv_pool_staged_fits(B, H, W, C, KH, KW, pad_t, pad_l, PH, PW, filters) -> bool:
+    """True when the fused first-layer kernels can stage whole images of this geometry in LDS (zero padding included):
+    they then read the unpadded input.  ``DTF_CONV_POOL_STAGED=0`` switches the staged form off."""
+    global _conv_pool_env_read
+    if not nv.kernels_available():
+        return False
+    lib = nv.kernels()
+    if not _conv_pool_env_read:
+        import os
+        _conv_pool_env_read = True
+        if os.environ.get("DTF_CONV_POOL_STAGED", "1") == "0":
+            lib.dtf_conv_pool_set_staged(0)
+    return bool(lib.dtf_conv_pool_staged_fits(int(B), int(H), int(W), int(C), int(KH), int(KW), int(pad_t), int(pad_l), int(PH),
+                                              int(PW), int(filters)))
+
+
 def conv_pool_workspace_floats(C, KH, KW, filters) -> int:
     k = nv.kernels()
     k.dtf_conv_pool_workspace_floats.restype = nv.c_ll

@@ -28,18 +28,30 @@ def _reference(x, w, b, act, padding, dpool):
     return y.detach().permute(0, 2, 3, 1), w.grad.permute(2, 3, 1, 0), b.grad
 
 
+@pytest.mark.parametrize("staged", [1, 2, 0], ids=["staged_in_lds", "staged_mfma_wgrad", "direct_from_global"])
 @pytest.mark.parametrize("B,H,W,C,KH,KW,Fo,padding,act", [
-    (5, 28, 28, 1, 5, 5, 32, "same", "relu"),        # the MNIST CNN's first layer
+    (5, 28, 28, 1, 5, 5, 32, "same", "relu"),        # the MNIST CNN's first layer; groups of two images, the last of one
     (3, 12, 10, 3, 3, 3, 64, "valid", "linear"),     # 27 taps, two channel groups, no activation, ragged last tile
     (1, 6, 6, 2, 2, 2, 32, "same", "relu"),          # 9 pooled pixels: one full tile and one nearly empty one
+    (37, 28, 28, 1, 5, 5, 32, "same", "relu"),       # an odd number of images: a short last group
 ])
-def test_fused_conv_pool_matches_pytorch(gpu_device, B, H, W, C, KH, KW, Fo, padding, act):
+def test_fused_conv_pool_matches_pytorch(gpu_device, B, H, W, C, KH, KW, Fo, padding, act, staged):
+    from distributed_tensorflow_amd.ops import _native as nv
+    nv.kernels().dtf_conv_pool_set_staged(staged)
+    try:
+        _check_fused_conv_pool(gpu_device, B, H, W, C, KH, KW, Fo, padding, act, staged)
+    finally:
+        nv.kernels().dtf_conv_pool_set_staged(1)
+
+
+def _check_fused_conv_pool(gpu_device, B, H, W, C, KH, KW, Fo, padding, act, staged):
     g = torch.Generator().manual_seed(B * 100 + H)
     x = torch.randn(B, H, W, C, generator=g).to(gpu_device)
     w = (torch.randn(KH, KW, C, Fo, generator=g) * 0.3).to(gpu_device)
     b = (torch.randn(Fo, generator=g) * 0.1).to(gpu_device)
     assert F.conv_pool_supported(x.shape, KH, KW, Fo, (1, 1), padding, (2, 2))
-    OH, OW = F.conv_geometry(H, W, KH, KW, (1, 1), padding)[:2]
+    OH, OW, pt, pl = F.conv_geometry(H, W, KH, KW, (1, 1), padding)[:4]
+    assert bool(F.conv_pool_staged_fits(B, H, W, C, KH, KW, pt, pl, OH // 2, OW // 2, Fo)) == bool(staged)
     ypool = torch.empty(B, OH // 2, OW // 2, Fo, device=gpu_device)
     arg = torch.empty(B, OH // 2, OW // 2, Fo, dtype=torch.uint8, device=gpu_device)
     code = ACT_CODES[act]
