@@ -73,6 +73,9 @@ class PeerRegion:
         self._shm = None
         self._peers_shm: List = []
         self._peer_views: List[Optional[torch.Tensor]] = [None] * self.world
+        # DTF_PEER_KERNELS=0: gather / scatter fall back to one runtime copy per peer (hipMemcpyAsync) instead of the
+        # kernels that load from / store to peer-mapped memory directly
+        self._kernels = os.environ.get("DTF_PEER_KERNELS", "1") != "0"
         if self.device.type == "cuda":
             self._init_gpu(cp, timeout_s)
         else:
@@ -166,7 +169,7 @@ class PeerRegion:
         self._check(dst[:n], src_off)
         if n == 0:
             return
-        if self._h is not None and n % 4 == 0 and src_off % 4 == 0:
+        if self._h is not None and n % 4 == 0 and src_off % 4 == 0 and self._kernels:
             rc = _k().dtf_mbox_gather(self._h, int(src_off) * 4, dst.data_ptr(), n * 4,
                                       torch.cuda.current_stream(self.device).cuda_stream)
             if rc:
@@ -184,7 +187,7 @@ class PeerRegion:
         self._check(src[:n], dst_off)
         if n == 0:
             return
-        if self._h is not None and n % 4 == 0 and dst_off % 4 == 0:
+        if self._h is not None and n % 4 == 0 and dst_off % 4 == 0 and self._kernels:
             rc = _k().dtf_mbox_scatter(self._h, int(dst_off) * 4, src.data_ptr(), n * 4,
                                        torch.cuda.current_stream(self.device).cuda_stream)
             if rc:
