@@ -163,6 +163,11 @@ class HeartbeatHook(SessionRunHook):
                                                 max_age_s=self.max_age_s, abort_after_s=self.abort_after_s)
             if self.detector is not None:
                 self.detector.start()
+        # a strategy that waits on shared-memory words (the asynchronous mode's doorbells) polls the detector while it
+        # waits: the loss of the task it is waiting for surfaces as ClusterLostError instead of a timeout
+        strategy = getattr(getattr(session, "engine", None), "strategy", None)
+        if self.detector is not None and strategy is not None and hasattr(strategy, "external_health_check"):
+            strategy.external_health_check = self.detector.check
 
     def before_run(self, run_context):
         if self.detector is not None:

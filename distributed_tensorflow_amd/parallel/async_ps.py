@@ -859,7 +859,12 @@ class AsyncPSStrategy:
         self.last_global_step = gs0
 
     # -- data movement: colocated owners (peer regions + doorbell words; nothing here crosses a socket)
+    #: set by the session's heartbeat hook: raises ClusterLostError when the failure detector has lost a task
+    external_health_check = None
+
     def _health(self):
+        if self.external_health_check is not None:
+            self.external_health_check()
         self._check_service()
         svc = self._service
         if svc is not None and svc.pump is not None and svc.pump.error():
