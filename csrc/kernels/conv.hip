@@ -158,6 +158,66 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
     }
 }
 
+
+// General max pooling: any window, any strides, VALID or SAME padding (TensorFlow's rule: padded positions never win,
+// the extra padding goes to the bottom / right).  Forward: one thread per output element, arg = window position of the
+// maximum.  Backward: one thread per INPUT element sums the gradients of the windows that cover it and chose it
+// (overlapping windows when a stride is smaller than its window) - a gather, so no atomics and a fixed summation order.
+struct PoolGeomS {
+    int B, H, W, C, PH, PW, SH, SW, OH, OW, pad_t, pad_l;
+};
+
+__global__ __launch_bounds__(256) void maxpool_strided_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                  unsigned char* __restrict__ arg, const PoolGeomS g,
+                                                                  long long total) {
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int c = (int)(idx % g.C);
+        const long long pix = idx / g.C;
+        const int ow = (int)(pix % g.OW);
+        const int oh = (int)((pix / g.OW) % g.OH);
+        const int b = (int)(pix / ((long long)g.OW * g.OH));
+        float best = -INFINITY;
+        int bi = 0;
+        for (int i = 0; i < g.PH; ++i) {
+            const int ih = oh * g.SH - g.pad_t + i;
+            if (ih < 0 || ih >= g.H) continue;
+            for (int j = 0; j < g.PW; ++j) {
+                const int iw = ow * g.SW - g.pad_l + j;
+                if (iw < 0 || iw >= g.W) continue;
+                const float v = x[(((long long)b * g.H + ih) * g.W + iw) * g.C + c];
+                if (v > best) { best = v; bi = i * g.PW + j; }
+            }
+        }
+        y[idx] = best;
+        arg[idx] = (unsigned char)bi;
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool_strided_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ arg,
+                                                                  const float* __restrict__ x_relu, float* __restrict__ dx,
+                                                                  const PoolGeomS g, long long total) {
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int c = (int)(idx % g.C);
+        const long long pix = idx / g.C;
+        const int iw = (int)(pix % g.W);
+        const int ih = (int)((pix / g.W) % g.H);
+        const int b = (int)(pix / ((long long)g.W * g.H));
+        // windows (oh, ow) with oh * SH - pad_t <= ih < oh * SH - pad_t + PH
+        const int py = ih + g.pad_t, px = iw + g.pad_l;
+        const int oh_lo = py - g.PH + 1 > 0 ? (py - g.PH + g.SH) / g.SH : 0;
+        const int ow_lo = px - g.PW + 1 > 0 ? (px - g.PW + g.SW) / g.SW : 0;
+        const int oh_hi = min(py / g.SH, g.OH - 1), ow_hi = min(px / g.SW, g.OW - 1);
+        float r = 0.f;
+        for (int oh = oh_lo; oh <= oh_hi; ++oh)
+            for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+                const long long o = (((long long)b * g.OH + oh) * g.OW + ow) * g.C + c;
+                if ((int)arg[o] == (py - oh * g.SH) * g.PW + (px - ow * g.SW)) r += dy[o];
+            }
+        if (x_relu && !(x_relu[idx] > 0.f)) r = 0.f;
+        dx[idx] = r;
+    }
+}
+
 // Four channels per thread (C % 4 == 0): 16-byte accesses and a quarter of the index arithmetic.
 __global__ __launch_bounds__(256) void maxpool_fwd4_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                            unsigned char* __restrict__ arg, const PoolGeom g, long long total) {
@@ -305,6 +365,31 @@ DTF_API int dtf_col2im(const float* dcols, float* dx, const float* yprev, int B,
         const long long total = (long long)B * H * W * C;
         hipLaunchKernelGGL(col2im_kernel<1>, dim3(grid_for(total)), dim3(256), 0, stream, dcols, dx, yprev, g, total);
     }
+    DTF_CHECK_LAUNCH();
+    return 0;
+}
+
+DTF_API int dtf_maxpool_strided_fwd(const float* x, float* y, unsigned char* arg, int B, int H, int W, int C, int PH, int PW,
+                                    int SH, int SW, int OH, int OW, int pad_t, int pad_l, hipStream_t stream) {
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || PH <= 0 || PW <= 0 || SH <= 0 || SW <= 0 || OH <= 0 || OW <= 0 ||
+        PH * PW > 255 || pad_t < 0 || pad_l < 0)
+        return -3;
+    const PoolGeomS g = {B, H, W, C, PH, PW, SH, SW, OH, OW, pad_t, pad_l};
+    const long long total = (long long)B * OH * OW * C;
+    hipLaunchKernelGGL(maxpool_strided_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, y, arg, g, total);
+    DTF_CHECK_LAUNCH();
+    return 0;
+}
+
+DTF_API int dtf_maxpool_strided_bwd(const float* dy, const unsigned char* arg, const float* x_relu, float* dx, int B, int H,
+                                    int W, int C, int PH, int PW, int SH, int SW, int OH, int OW, int pad_t, int pad_l,
+                                    hipStream_t stream) {
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || PH <= 0 || PW <= 0 || SH <= 0 || SW <= 0 || OH <= 0 || OW <= 0 ||
+        PH * PW > 255 || pad_t < 0 || pad_l < 0)
+        return -3;
+    const PoolGeomS g = {B, H, W, C, PH, PW, SH, SW, OH, OW, pad_t, pad_l};
+    const long long total = (long long)B * H * W * C;
+    hipLaunchKernelGGL(maxpool_strided_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, dy, arg, x_relu, dx, g, total);
     DTF_CHECK_LAUNCH();
     return 0;
 }

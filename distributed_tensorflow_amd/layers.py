@@ -563,17 +563,22 @@ class Conv2D(Layer):
 
 
 class MaxPooling2D(Layer):
-    """Non-overlapping NHWC max pooling (``strides`` = ``pool_size``, VALID), the Keras default."""
+    """NHWC max pooling.  The Keras default - ``strides`` = ``pool_size``, ``padding='valid'`` - takes the fast kernels
+    (and can run inside the convolution in front); any other strides or ``padding='same'`` take the general ones."""
 
     prefix = "max_pooling2d"
 
     def __init__(self, pool_size=(2, 2), strides=None, padding: str = "valid", name=None):
         super().__init__(name=name)
         self.pool_size = _pair(pool_size)
-        if strides is not None and _pair(strides) != self.pool_size:
-            raise NotImplementedError("MaxPooling2D supports strides == pool_size")
-        if str(padding).lower() != "valid":
-            raise NotImplementedError("MaxPooling2D supports padding='valid'")
+        self.strides = _pair(strides) if strides is not None else self.pool_size
+        self.padding = str(padding).lower()
+        if self.padding not in ("valid", "same"):
+            raise ValueError("MaxPooling2D: padding must be 'valid' or 'same'")
+        if self.pool_size[0] * self.pool_size[1] > 255:
+            raise ValueError("MaxPooling2D: windows of more than 255 positions are not supported")
+        # windows that tile the image: the case the fused / vectorised kernels cover
+        self.tiling = self.strides == self.pool_size and self.padding == "valid"
         self.fold_relu_grad = False      # the pooled tensor is a ReLU output whose gradient this layer applies
         self.fused_into = None           # the Conv2D in front, when the pair may run as one kernel
         self._buf = _Buffers()
@@ -583,7 +588,10 @@ class MaxPooling2D(Layer):
         if len(input_shape) != 3:
             raise ValueError("MaxPooling2D expects per-example shape (H, W, C), got %s" % (input_shape,))
         H, W, C = input_shape
-        OH, OW = H // self.pool_size[0], W // self.pool_size[1]
+        if self.tiling:
+            OH, OW = H // self.pool_size[0], W // self.pool_size[1]
+        else:
+            OH, OW = F.pool_geometry(H, W, *self.pool_size, self.strides, self.padding)[:2]
         if OH <= 0 or OW <= 0:
             raise ValueError("pool %s does not fit input %s" % (self.pool_size, input_shape))
         return (OH, OW, C)
@@ -604,7 +612,10 @@ class MaxPooling2D(Layer):
         shape = (B,) + tuple(self.output_shape)
         y = self._buf.get("y", shape, x.device)
         arg = self._arg_buffer(shape, x.device)
-        F.maxpool_forward(x, self.pool_size, out=y, arg=arg)
+        if self.tiling:
+            F.maxpool_forward(x, self.pool_size, out=y, arg=arg)
+        else:
+            F.maxpool_strided_forward(x, self.pool_size, self.strides, self.padding, out=y, arg=arg)
         self._x, self._arg = x, arg
         return y
 
@@ -621,11 +632,15 @@ class MaxPooling2D(Layer):
                                       self._ypool if self.fold_relu_grad else None, out=dx, mask_pooled=True)
         x = self._x
         dx = self._buf.get("dx", x.shape, x.device)
+        if not self.tiling:
+            return F.maxpool_strided_backward(dy.contiguous(), self._arg, x.shape, self.pool_size, self.strides, self.padding,
+                                              x if self.fold_relu_grad else None, out=dx)
         return F.maxpool_backward(dy.contiguous(), self._arg, x.shape, self.pool_size,
                                   x if self.fold_relu_grad else None, out=dx)
 
     def get_config(self):
-        return {"class": "MaxPooling2D", "name": self.name, "pool_size": self.pool_size}
+        return {"class": "MaxPooling2D", "name": self.name, "pool_size": self.pool_size, "strides": self.strides,
+                "padding": self.padding}
 
 
 def layer_from_config(cfg: dict) -> Layer:

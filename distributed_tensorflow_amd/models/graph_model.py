@@ -152,7 +152,7 @@ class GraphModel(Sequential):
             return A.conv2d(x, self._leaf(layer.kernel), b, layer.strides, layer.padding,
                             {0: None, 1: "relu", 2: "sigmoid"}[layer.act])
         if isinstance(layer, L.MaxPooling2D):
-            return A.max_pool2d(x, layer.pool_size)
+            return A.max_pool2d(x, layer.pool_size, layer.strides, layer.padding)
         raise NotImplementedError("layer %s is not supported in a graph model" % type(layer).__name__)
 
     def _eval(self, node, env: dict, training: bool):

@@ -145,7 +145,7 @@ class Sequential:
             elif isinstance(a, Conv2D) and a.act == ACT_RELU and isinstance(b, MaxPooling2D):
                 b.fold_relu_grad = True          # pooling backward also applies the conv's ReLU gradient
                 a.grad_is_dz = True
-            if isinstance(a, Conv2D) and isinstance(b, MaxPooling2D) and b.pool_size == (2, 2) \
+            if isinstance(a, Conv2D) and isinstance(b, MaxPooling2D) and b.pool_size == (2, 2) and b.tiling \
                     and a.act in (ACT_NONE, ACT_RELU):
                 # the pair may run with the pooling inside the convolution's kernel (decided per call: GPU, shape):
                 # the first-layer kernel of conv_pool.hip, or the pooling epilogue of the implicit-GEMM convolution

@@ -80,6 +80,8 @@ def kernels():
         "dtf_im2col": [c_p, c_p] + [c_i] * 12 + [c_p],
         "dtf_col2im": [c_p, c_p, c_p] + [c_i] * 12 + [c_p],
         "dtf_maxpool_fwd": [c_p, c_p, c_p] + [c_i] * 6 + [c_p],
+        "dtf_maxpool_strided_fwd": [c_p, c_p, c_p] + [c_i] * 12 + [c_p],
+        "dtf_maxpool_strided_bwd": [c_p, c_p, c_p, c_p] + [c_i] * 12 + [c_p],
         "dtf_conv_pool_supported": [c_i] * 4,
         "dtf_conv_pool_workspace_floats": [c_i] * 4,
         "dtf_conv_pool_set_staged": [c_i],

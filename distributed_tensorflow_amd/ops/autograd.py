@@ -199,23 +199,30 @@ def conv2d(x, w, b=None, strides=(1, 1), padding="valid", activation=None):
 
 class _MaxPoolFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, pool):
+    def forward(ctx, x, pool, strides, padding):
         x = _c(x)
-        y, arg = F.maxpool_forward(x, pool)
+        tiling = strides == pool and padding == "valid"
+        if tiling:
+            y, arg = F.maxpool_forward(x, pool)
+        else:
+            y, arg = F.maxpool_strided_forward(x, pool, strides, padding)
         ctx.save_for_backward(arg)
-        ctx.cfg = (tuple(x.shape), pool)
+        ctx.cfg = (tuple(x.shape), pool, strides, padding, tiling)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         (arg,) = ctx.saved_tensors
-        xshape, pool = ctx.cfg
-        return F.maxpool_backward(_c(dy), arg, xshape, pool), None
+        xshape, pool, strides, padding, tiling = ctx.cfg
+        if tiling:
+            return F.maxpool_backward(_c(dy), arg, xshape, pool), None, None, None
+        return F.maxpool_strided_backward(_c(dy), arg, xshape, pool, strides, padding), None, None, None
 
 
-def max_pool2d(x, pool=(2, 2)):
-    """Non-overlapping max pooling of an NHWC tensor (window = stride, VALID)."""
-    return _MaxPoolFn.apply(x, tuple(pool))
+def max_pool2d(x, pool=(2, 2), strides=None, padding="valid"):
+    """Max pooling of an NHWC tensor: any window and strides (default: strides = window), VALID or SAME padding."""
+    pool = tuple(pool)
+    return _MaxPoolFn.apply(x, pool, tuple(strides) if strides is not None else pool, str(padding).lower())
 
 
 # ----------------------------------------------------------------------------------------------- torch.nn modules
@@ -252,9 +259,9 @@ class Conv2D(torch.nn.Module):
 
 
 class MaxPooling2D(torch.nn.Module):
-    def __init__(self, pool_size=(2, 2)):
+    def __init__(self, pool_size=(2, 2), strides=None, padding="valid"):
         super().__init__()
-        self.pool_size = tuple(pool_size)
+        self.pool_size, self.strides, self.padding = tuple(pool_size), strides, padding
 
     def forward(self, x):
-        return max_pool2d(x, self.pool_size)
+        return max_pool2d(x, self.pool_size, self.strides, self.padding)

@@ -608,6 +608,74 @@ def maxpool_forward(x, pool=(2, 2), out=None, arg=None):
     return out, arg
 
 
+def pool_geometry(H, W, PH, PW, strides, padding="valid"):
+    """``(OH, OW, pad_top, pad_left)`` of a pooling window, TensorFlow rules ('same': out = ceil(in / stride), the extra
+    padding goes to the bottom / right; padded positions never win a maximum)."""
+    SH, SW = strides
+    if str(padding).lower() == "same":
+        OH, OW = -(-H // SH), -(-W // SW)
+        pt = max((OH - 1) * SH + PH - H, 0) // 2
+        pl = max((OW - 1) * SW + PW - W, 0) // 2
+    else:
+        OH, OW = (H - PH) // SH + 1, (W - PW) // SW + 1
+        pt = pl = 0
+    return OH, OW, pt, pl
+
+
+def maxpool_strided_forward(x, pool=(2, 2), strides=(2, 2), padding="valid", out=None, arg=None):
+    """Max pooling of an NHWC tensor with any window, strides and VALID / SAME padding; returns ``(y, arg)`` with
+    ``arg`` the window position ``i * PW + j`` of each maximum."""
+    B, H, W, C = x.shape
+    PH, PW = pool
+    SH, SW = strides
+    OH, OW, pt, pl = pool_geometry(H, W, PH, PW, strides, padding)
+    if out is None:
+        out = torch.empty((B, OH, OW, C), dtype=torch.float32, device=x.device)
+    if arg is None:
+        arg = torch.empty((B, OH, OW, C), dtype=torch.uint8, device=x.device)
+    if x.is_cuda:
+        nv.require_f32_contig(x, out)
+        rc = nv.kernels().dtf_maxpool_strided_fwd(nv.ptr(x), nv.ptr(out), nv.ptr(arg), B, H, W, C, PH, PW, SH, SW, OH, OW, pt,
+                                                  pl, nv.stream_ptr())
+        nv.check(rc, "dtf_maxpool_strided_fwd")
+        return out, arg
+    pb, pr = max((OH - 1) * SH + PH - H - pt, 0), max((OW - 1) * SW + PW - W - pl, 0)
+    xp = torch.nn.functional.pad(x.permute(0, 3, 1, 2), (pl, pr, pt, pb), value=float("-inf"))
+    u = torch.nn.functional.unfold(xp, (PH, PW), stride=(SH, SW)).view(B, C, PH * PW, OH * OW)
+    v, i = u.max(dim=2)                                       # first maximum in (i, j) order, as the kernel's scan
+    out.copy_(v.view(B, C, OH, OW).permute(0, 2, 3, 1))
+    arg.copy_(i.view(B, C, OH, OW).permute(0, 2, 3, 1).to(torch.uint8))
+    return out, arg
+
+
+def maxpool_strided_backward(dy, arg, x_shape, pool=(2, 2), strides=(2, 2), padding="valid", x_relu=None, out=None):
+    """Gradient of ``maxpool_strided_forward``: every input element receives the gradients of the windows that chose
+    it (summed where windows overlap); ``x_relu`` (the pooling's input) folds the gradient of a ReLU in front in."""
+    B, H, W, C = x_shape
+    PH, PW = pool
+    SH, SW = strides
+    OH, OW, pt, pl = pool_geometry(H, W, PH, PW, strides, padding)
+    if out is None:
+        out = torch.empty(tuple(x_shape), dtype=torch.float32, device=dy.device)
+    if dy.is_cuda:
+        nv.require_f32_contig(dy, out, x_relu)
+        rc = nv.kernels().dtf_maxpool_strided_bwd(nv.ptr(dy), nv.ptr(arg), nv.ptr(x_relu), nv.ptr(out), B, H, W, C, PH, PW, SH,
+                                                  SW, OH, OW, pt, pl, nv.stream_ptr())
+        nv.check(rc, "dtf_maxpool_strided_bwd")
+        return out
+    a = arg.to(torch.int64)
+    oh = torch.arange(OH).view(1, OH, 1, 1)
+    ow = torch.arange(OW).view(1, 1, OW, 1)
+    ih = oh * SH - pt + a // PW                                # input position every window chose
+    iw = ow * SW - pl + a % PW
+    flat = ((torch.arange(B).view(B, 1, 1, 1) * H + ih) * W + iw) * C + torch.arange(C).view(1, 1, 1, C)
+    out.zero_()
+    out.view(-1).index_add_(0, flat.reshape(-1), dy.reshape(-1))
+    if x_relu is not None:
+        out.mul_((x_relu > 0).to(out.dtype))
+    return out
+
+
 def conv_pool_supported(x_shape, KH, KW, filters, strides=(1, 1), padding="valid", pool=(2, 2)) -> bool:
     """True when a convolution followed by 2x2 max pooling can run as the fused first-layer kernels
     (csrc/kernels/conv_pool.hip): stride 1, KH*KW*Cin < 32, filters a multiple of 32, even conv output size."""

@@ -121,8 +121,9 @@ def test_mnist_cnn_shape_and_one_step():
     assert m.predict(x).shape == (4, 10)
     with pytest.raises(ValueError):
         Conv2D(4, 3, padding="full")
-    with pytest.raises(NotImplementedError):
-        MaxPooling2D((2, 2), strides=(1, 1))
+    assert not MaxPooling2D((2, 2), strides=(1, 1)).tiling and MaxPooling2D((2, 2)).tiling     # overlapping windows: general kernels
+    with pytest.raises(ValueError):
+        MaxPooling2D((2, 2), padding="full")
 
 
 def test_masked_implicit_tables_switch_off_above_2_to_30_elements():
@@ -134,3 +135,59 @@ def test_masked_implicit_tables_switch_off_above_2_to_30_elements():
     assert not fit(85600, 14, 14, 64, 14, 14, 64, 5, 5, False)                # input: 85600*14*14*64 >= 2^30
     assert fit(85000, 14, 14, 32, 14, 14, 64, 5, 5, False)
     assert not fit(85600, 14, 14, 32, 14, 14, 64, 5, 5, True)                 # dgrad gathers the 64-channel output gradient
+
+
+import pytest as _pytest
+
+
+def _pool_reference(x, pool, strides, padding):
+    """fp64 PyTorch: TensorFlow-style SAME padding (extra at the bottom / right, padded positions never win)."""
+    import torch
+    xr = x.double().permute(0, 3, 1, 2).clone().requires_grad_(True)
+    H, W = x.shape[1], x.shape[2]
+    xin = xr
+    if padding == "same":
+        oh, ow = -(-H // strides[0]), -(-W // strides[1])
+        th, tw = max((oh - 1) * strides[0] + pool[0] - H, 0), max((ow - 1) * strides[1] + pool[1] - W, 0)
+        xin = torch.nn.functional.pad(xr, (tw // 2, tw - tw // 2, th // 2, th - th // 2), value=float("-inf"))
+    y = torch.nn.functional.max_pool2d(xin, pool, stride=strides)
+    return xr, y
+
+
+POOL_CASES = [((3, 3), (2, 2), "same"), ((3, 3), (1, 1), "valid"), ((2, 2), (2, 2), "same"), ((3, 2), (2, 1), "same"),
+              ((2, 2), (3, 3), "valid")]
+
+
+@_pytest.mark.parametrize("pool,strides,padding", POOL_CASES)
+def test_general_max_pooling_matches_pytorch(pool, strides, padding):
+    """Overlapping windows, strides larger than the window, SAME padding on odd sizes: values, arg-max routing and the
+    summed gradient of overlapping windows against PyTorch autograd."""
+    import torch
+    from distributed_tensorflow_amd.ops import functional as F
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(3, 9, 7, 5, generator=g)
+    y, arg = F.maxpool_strided_forward(x, pool, strides, padding)
+    xr, yr = _pool_reference(x, pool, strides, padding)
+    assert tuple(y.shape) == tuple(yr.permute(0, 2, 3, 1).shape)
+    torch.testing.assert_close(y.double(), yr.detach().permute(0, 2, 3, 1))
+    dy = torch.randn(y.shape, generator=g)
+    yr.backward(dy.double().permute(0, 3, 1, 2))
+    dx = F.maxpool_strided_backward(dy, arg, x.shape, pool, strides, padding)
+    torch.testing.assert_close(dx.double(), xr.grad.permute(0, 2, 3, 1), rtol=1e-6, atol=1e-6)
+
+
+def test_cnn_with_overlapping_same_pooling_trains():
+    import torch
+    from distributed_tensorflow_amd.layers import Conv2D, Dense, Flatten, MaxPooling2D
+    from distributed_tensorflow_amd.models import Sequential
+    m = Sequential([Conv2D(8, (3, 3), padding="same", activation="relu", input_shape=(9, 9, 1)),
+                    MaxPooling2D((3, 3), strides=(2, 2), padding="same"), Flatten(), Dense(4, activation="softmax")])
+    m.compile(loss="sparse_categorical_crossentropy", optimizer="adam", metrics=["accuracy"], device="cpu", seed=1)
+    assert m.layers[1].output_shape == (5, 5, 8) and not m.layers[1].tiling
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(64, 9, 9, 1, generator=g)
+    y = (x.mean(dim=(1, 2, 3)) > 0).long() + 2 * (x[:, :4].mean(dim=(1, 2, 3)) > 0).long()
+    first = m.train_on_batch(x, y)["loss"]
+    for _ in range(60):
+        last = m.train_on_batch(x, y)["loss"]
+    assert last < 0.7 * first

@@ -228,3 +228,22 @@ def test_unpadded_gather_and_pooling_epilogue(gpu_device, g):
         # CPU reference of the pooled-mask variant
         cpu = F.maxpool_backward(dyp.cpu(), arg.cpu(), (B, OH, OW, N), (2, 2), x_relu=yp.view(yp_ref.shape).cpu(), mask_pooled=True)
         assert torch.equal(cpu, full.cpu())
+
+
+@pytest.mark.parametrize("pool,strides,padding", [((3, 3), (2, 2), "same"), ((3, 3), (1, 1), "valid"), ((2, 2), (2, 2), "same"),
+                                                  ((3, 2), (2, 1), "same"), ((2, 2), (3, 3), "valid")])
+def test_general_max_pooling_kernels_match_the_cpu_path(gpu_device, pool, strides, padding):
+    """The strided / SAME-padded pooling kernels against the CPU implementation (itself checked against PyTorch autograd
+    in tests/test_conv_cpu.py): values, arg-max and the gradient summed over overlapping windows."""
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(4, 13, 10, 6, generator=g)
+    y, arg = F.maxpool_strided_forward(x, pool, strides, padding)
+    yg, argg = F.maxpool_strided_forward(x.to(gpu_device), pool, strides, padding)
+    assert torch.equal(yg.cpu(), y) and torch.equal(argg.cpu(), arg)
+    dy = torch.randn(y.shape, generator=g)
+    xr = torch.relu(x)
+    for relu in (None, xr):
+        dx = F.maxpool_strided_backward(dy, arg, x.shape, pool, strides, padding, x_relu=relu)
+        dxg = F.maxpool_strided_backward(dy.to(gpu_device), argg, x.shape, pool, strides, padding,
+                                         x_relu=None if relu is None else relu.to(gpu_device))
+        torch.testing.assert_close(dxg.cpu(), dx, rtol=1e-6, atol=1e-6)
