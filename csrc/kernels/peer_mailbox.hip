@@ -21,7 +21,8 @@ constexpr int MBOX_MAX_RANKS = 64;
 
 struct Mailbox {
     int rank = 0, world = 0;
-    size_t bytes = 0;
+    size_t bytes = 0;                      // this rank's region
+    size_t size[MBOX_MAX_RANKS] = {};      // every rank's region (equal unless dtf_mbox_set_peer_bytes says otherwise)
     void* local = nullptr;
     void* peer[MBOX_MAX_RANKS] = {};       // peer[rank] == local
     bool opened[MBOX_MAX_RANKS] = {};
@@ -52,10 +53,10 @@ __global__ __launch_bounds__(256) void peer_shards_kernel(PeerTable peers, long 
 int launch_peer_shards(Mailbox* m, bool gather, long long off, void* local, long long shard_bytes, hipStream_t stream) {
     if (shard_bytes == 0) return 0;
     if (off < 0 || shard_bytes < 0 || (shard_bytes & 15) || (off & 15) || (reinterpret_cast<uintptr_t>(local) & 15)) return -3;
-    if ((size_t)off + (size_t)shard_bytes > m->bytes) return -3;
     PeerTable t;
     for (int r = 0; r < m->world; ++r) {
         if (!m->peer[r]) return -2;
+        if ((size_t)off + (size_t)shard_bytes > m->size[r]) return -3;
         t.ptr[r] = static_cast<char*>(m->peer[r]);
     }
     const long long n16 = shard_bytes / 16;
@@ -97,7 +98,18 @@ DTF_API void* dtf_mbox_create(int rank, int world, long long bytes) {
         return nullptr;
     }
     m->peer[rank] = m->local;
+    for (int r = 0; r < world; ++r) m->size[r] = m->bytes;
     return m;
+}
+
+// Regions need not be equally sized (parameter-server tasks hold slots and inboxes, their workers hold nothing): tells
+// this rank how large rank `r`'s region is, for the bounds checks of put / get / gather / scatter.
+DTF_API int dtf_mbox_set_peer_bytes(void* h, int r, long long bytes) {
+    auto* m = static_cast<Mailbox*>(h);
+    if (r < 0 || r >= m->world || bytes < 0) return -2;
+    if (r == m->rank) return (size_t)bytes <= m->bytes ? 0 : -3;
+    m->size[r] = (size_t)bytes;
+    return 0;
 }
 
 DTF_API int dtf_mbox_handle_bytes() { return (int)sizeof(hipIpcMemHandle_t); }
@@ -136,7 +148,7 @@ DTF_API int dtf_mbox_put(void* h, int peer, long long dst_off, const void* src, 
     auto* m = static_cast<Mailbox*>(h);
     if (peer < 0 || peer >= m->world || !m->peer[peer]) return -2;
     if (bytes == 0) return 0;
-    if (dst_off < 0 || bytes < 0 || (size_t)dst_off + (size_t)bytes > m->bytes) return -3;     // regions are equally sized
+    if (dst_off < 0 || bytes < 0 || (size_t)dst_off + (size_t)bytes > m->size[peer]) return -3;
     return (int)hipMemcpyAsync(static_cast<char*>(m->peer[peer]) + dst_off, src, (size_t)bytes, hipMemcpyDefault, stream);
 }
 
@@ -145,7 +157,7 @@ DTF_API int dtf_mbox_get(void* h, int peer, long long src_off, void* dst, long l
     auto* m = static_cast<Mailbox*>(h);
     if (peer < 0 || peer >= m->world || !m->peer[peer]) return -2;
     if (bytes == 0) return 0;
-    if (src_off < 0 || bytes < 0 || (size_t)src_off + (size_t)bytes > m->bytes) return -3;
+    if (src_off < 0 || bytes < 0 || (size_t)src_off + (size_t)bytes > m->size[peer]) return -3;
     return (int)hipMemcpyAsync(dst, static_cast<const char*>(m->peer[peer]) + src_off, (size_t)bytes, hipMemcpyDefault, stream);
 }
 

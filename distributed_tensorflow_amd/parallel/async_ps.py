@@ -25,14 +25,18 @@ Re-designed for one MI355X node:
   two inbox slots per worker the next forward pass starts while the owners are still applying (that lag is
   part of the staleness bound).  Version, staleness, ``global_step`` and the workers' clocks ride in the words;
 * **ps tasks as owners** (separate processes, as in the reference; whole variables placed
-  round-robin or byte-balanced): one packed gradient message to and one packed parameter message
-  from every owner per step over ``torch.distributed`` send/recv - RCCL between GPUs, gloo between
-  CPU processes - instead of TF's one RecvTensor RPC per variable per direction.  Each process
-  has exactly one thread on the data plane;
-* with ps tasks as owners control traffic is folded: per step a worker makes one round trip per control server to
-  queue its requests, one to collect the replies (which carry the owner's version, the observed staleness and
-  the new ``global_step``), and - with a staleness bound - one to publish its clock and wait.  The control plane
-  otherwise serves rendezvous, barriers, heartbeats, checkpoints and shutdown;
+  round-robin or byte-balanced).  On one node, with ps tasks and workers on the same kind of device, they use the
+  same one-sided plane: every ps task allocates a region (its packed variables, two slot planes, inbox slots),
+  workers put the flat ranges of an owner's variables into their inbox slot and get them back from its variable
+  plane, doorbells and the native pump do the rest - no process group, no socket on the step path;
+* ps tasks on other nodes, or on another kind of device than their workers (``DTF_PS_DATA_PLANE=p2p`` forces it):
+  one packed gradient message to and one packed parameter message from every owner per step over
+  ``torch.distributed`` send/recv - RCCL between GPUs, gloo between CPU processes - instead of TF's one RecvTensor
+  RPC per variable per direction, each process with exactly one thread on the data plane.  Control traffic is
+  folded: per step a worker makes one round trip per control server to queue its requests, one to collect the
+  replies (which carry the owner's version, the observed staleness and the new ``global_step``), and - with a
+  staleness bound - one to publish its clock and wait.  The control plane otherwise serves rendezvous, barriers,
+  heartbeats, checkpoints and shutdown;
 * *bounded staleness* (stale-synchronous parallel): a worker that has completed ``c`` pushes may
   start its next step only while ``c - min(all clocks) <= max_staleness``.  ``max_staleness=None``
   is the reference's unbounded behaviour.  The observed staleness of every push (owner version at
@@ -128,6 +132,19 @@ def _unpack(buf: torch.Tensor, flat: torch.Tensor, ranges):
         if buf.data_ptr() != flat[b:e].data_ptr():
             flat[b:e].copy_(buf[pos:pos + e - b])
         pos += e - b
+
+
+def region_sizes(stride: int, depth: int, num_ps: int, num_workers: int) -> List[int]:
+    """Floats per rank of the peer regions of a cluster whose ps tasks are the owners (ranks: ps tasks, then workers):
+    variables + two slot planes + ``depth`` inbox slots per worker on a ps task, a token allocation on a worker."""
+    return [3 * stride + num_workers * depth * stride] * num_ps + [64] * num_workers
+
+
+_LOOPBACK = {"localhost", "127.0.0.1", "0.0.0.0", "::1"}
+
+
+def split_host(address: str) -> str:
+    return address.rsplit(":", 1)[0]
 
 
 def _numel(shape) -> int:
@@ -227,9 +244,11 @@ class _P2P:
 class ParameterServerService:
     """Owner of a set of flat ranges: serves init / pushpull / pull / save / restore / stats / shutdown.
 
-    Two data planes: ``region`` (a :class:`~.peer_region.PeerRegion` shared with the workers: colocated owners) or
-    ``p2p`` (``torch.distributed`` send/recv: ps tasks).  Layout of a region, in floats, with ``S`` the shard length
-    ``flat_len / owners``, ``W`` workers and ``D`` inbox slots per worker:
+    Two data planes: ``region`` (a :class:`~.peer_region.PeerRegion` shared with the workers: colocated owners, and
+    ps tasks that share a node and a device type with their workers) or ``p2p`` (``torch.distributed`` send/recv: ps
+    tasks on other nodes or other kinds of device).  Layout of a region, in floats, with ``S`` the layout's
+    ``stride`` (the shard length ``flat_len / owners`` of colocated owners; the largest owner's element count, rounded
+    up, for ps tasks), ``W`` workers and ``D`` inbox slots per worker:
 
     * ``[0, S)``                       this owner's variables (workers read them with one-sided gets);
     * ``[S, 2S)`` and ``[2S, 3S)``     its optimizer slots (Adam m and v / momentum): nobody else holds any;
@@ -275,6 +294,7 @@ class ParameterServerService:
         self.blocks = None                  # doorbell.ControlBlocks (region mode)
         self.depth = 1
         self.pump = None
+        self._owns_region = False           # a ps task maps its region itself, after it has read the layout
 
     # a tiny VariableStore look-alike so Optimizer.apply works on the owned shard
     class _Shard:
@@ -309,6 +329,21 @@ class ParameterServerService:
                            master_port=port, device=self.device if backend == "nccl" else None)
         self._owns_group = True
 
+    def _join_region_plane(self, layout: dict):
+        """ps task: allocate this owner's region and control block and map everybody else's (collective with the other
+        ps tasks and all workers; the ps tasks are the first ranks)."""
+        from .doorbell import ControlBlocks
+        from .peer_region import PeerRegion
+        srv = self.server
+        world = self.num_owners + self.num_workers
+        self.depth = int(layout["depth"])
+        sizes = region_sizes(int(layout["stride"]), self.depth, self.num_owners, self.num_workers)
+        self.region = PeerRegion(self.rank, world, sizes[self.rank], self.device, self.cp0, name=self.ns + "/region",
+                                 sizes=sizes)
+        self.blocks = ControlBlocks(self.rank, world, self.cp0, name=self.ns + "/ctl", lanes=self.num_workers,
+                                    owner_rank=srv.ps_rank)
+        self._owns_region = True
+
     def _configure(self, layout: dict):
         from .. import optimizers
         self.layout = layout
@@ -318,7 +353,7 @@ class ParameterServerService:
         self.flat_len = int(layout["flat_len"])
         n = self.n = _ranges_numel(self.ranges)
         if self.region is not None:
-            self.slot_len = self.flat_len // self.num_owners
+            self.slot_len = int(layout.get("stride", self.flat_len // self.num_owners))
             self.var = self.region.local[0:max(n, 1)]
             self.grad = None
         else:
@@ -387,6 +422,11 @@ class ParameterServerService:
         # the chief posts the layout; a cluster that trains without its ps tasks (synchronous replicas,
         # colocated owners) only ever sends "shutdown"
         layout = None
+        if self.region is None:
+            # what the chief needs to choose the data plane: where this ps task runs and on which kind of device
+            import socket
+            self.cp0.set("%s/where/%d" % (self.ns, self.owner_index),
+                         ("%s@%s" % (self.device.type, socket.gethostname())).encode())
         while layout is None:
             try:
                 layout = self.cp.get_json("%s/layout/%d" % (self.ns, self.owner_index), timeout_s=0.5)
@@ -402,9 +442,13 @@ class ParameterServerService:
             # the rare requests (initialisation, checkpoints)
             self.stream = torch.cuda.Stream(device=self.device)
         if self.region is None and self.p2p is None:
-            self._join_data_plane()      # only clusters that use their ps tasks put them on the data plane
-            self.p2p = _P2P(self.rank)
-            self.p2p.make_direction_groups()
+            # only clusters that use their ps tasks put them on the data plane
+            if layout.get("plane") == "region":
+                self._join_region_plane(layout)
+            else:
+                self._join_data_plane()
+                self.p2p = _P2P(self.rank)
+                self.p2p.make_direction_groups()
         ctx = torch.cuda.stream(self.stream) if self.stream is not None else _NullContext()
         with ctx:
             self._configure(layout)
@@ -415,6 +459,11 @@ class ParameterServerService:
                 if self.pump is not None:
                     pump, self.pump = self.pump, None
                     pump.stop()
+                if self._owns_region:
+                    self.var = self.shard = None
+                    self.slots = {}
+                    self.region.close()
+                    self.blocks.close()
         self.cp0.add(self.ns + "/stopped", 1)
         if self._owns_group and dist.is_initialized():
             try:
@@ -627,7 +676,8 @@ class AsyncPSStrategy:
         self._staging: Dict = {}
         self.region = None
         self.p2p = None
-        self.blocks = None            # doorbell.ControlBlocks: the owners' words (colocated owners)
+        self.plane = None             # "region" (peer regions + doorbell words) or "p2p" (send/recv), set by prepare
+        self.blocks = None            # doorbell.ControlBlocks: the owners' words (region plane)
         self.depth = 1                # inbox slots per (owner, worker): gradients a worker may have outstanding
         self._pulled: List[int] = []  # owner versions seen at the last pull
         self._sent_pulled: List[List[int]] = []   # [slot][owner]: the same, as sent along with the gradient in that slot
@@ -738,6 +788,9 @@ class AsyncPSStrategy:
         # does any variable straddle two owners?  (then a checkpoint assembles it in its writer's staging area)
         self.gather = any(p["n"] != p["numel"] for j in range(self.num_owners)
                           for p in owned_pieces(self.var_table, self.ranges[j]))
+        import os
+        depth = 1 if (self.max_staleness == 0 or store.flat_len * 4 > (1 << 30)) else 2
+        depth = max(1, min(4, int(os.environ.get("DTF_ASYNC_INBOX_DEPTH", depth))))
         if self.colocated:
             # one-sided data plane.  A rank's region: its variable shard, its two optimizer-slot shards, and
             # `depth` inbox slots per worker.  Two slots let a worker compute its next step while the owners still
@@ -745,21 +798,14 @@ class AsyncPSStrategy:
             # model whose second set of slots would cost more than a gigabyte per rank.
             from .doorbell import ControlBlocks
             from .peer_region import PeerRegion
-            import os
             S = self.slot_len = store.flat_len // self.num_owners
-            depth = 1 if (self.max_staleness == 0 or store.flat_len * 4 > (1 << 30)) else 2
-            self.depth = max(1, min(4, int(os.environ.get("DTF_ASYNC_INBOX_DEPTH", depth))))
+            self.depth = depth
+            self.plane = "region"
             self.region_floats = 3 * S + self.num_workers * self.depth * S
             self.region = PeerRegion(self.worker_index, self.num_workers, self.region_floats, dev, self.cp0,
                                      name="co/region", timeout_s=self.timeout_s)
             self.blocks = ControlBlocks(self.worker_index, self.num_workers, self.cp0, name="co/ctl",
                                         timeout_s=self.timeout_s)
-            self._pulled = [0] * self.num_owners
-            self._sent_pulled = [[0] * self.num_owners for _ in range(self.depth)]
-            self._acked = [0] * self.num_owners
-            if dev.type == "cuda":
-                self._comm_stream = torch.cuda.Stream(device=dev)
-                self._ev_grad, self._ev_copied = torch.cuda.Event(), torch.cuda.Event()
             svc = ParameterServerService(server=srv, owner_index=self.worker_index,
                                          control=ControlClient(*srv.control_address(0), timeout_s=self.timeout_s),
                                          control0=ControlClient(*srv.control_address(0), timeout_s=self.timeout_s),
@@ -770,14 +816,37 @@ class AsyncPSStrategy:
             self._service = svc
             self._service_thread = threading.Thread(target=self._run_service, name="dtf-owner-%d" % self.worker_index,
                                                     daemon=True)
+            plane = {"plane": "region", "stride": S, "depth": self.depth}
+        elif srv.is_chief:
+            plane = self._choose_plane(dev, depth)
+            self.cp0.set_json(self.ns + "/plane", plane)
+        else:
+            plane = self.cp0.get_json(self.ns + "/plane", timeout_s=self.timeout_s)
         if srv.is_chief:
             layout = {"ranges": self.ranges, "optimizer": opt_desc, "flat_len": store.flat_len,
                       "variables": self.var_table}
+            layout.update(plane)
             for c, js in self._distinct_cps():
                 for j in js:
                     c.set_json("%s/layout/%d" % (self.ns, j), layout)
-        if not self.colocated:
+        if not self.colocated and plane["plane"] == "region":
+            # the ps tasks' regions and control blocks (after the layout is out: they map them once they have it)
+            from .doorbell import ControlBlocks
+            from .peer_region import PeerRegion
+            if dev.type != plane["device"]:
+                raise RuntimeError("worker %d computes on %s, but the cluster's one-sided data plane is between %s "
+                                   "devices: set DTF_PS_DATA_PLANE=p2p" % (self.worker_index, dev.type, plane["device"]))
+            self.plane = "region"
+            self.slot_len, self.depth = int(plane["stride"]), int(plane["depth"])
+            sizes = region_sizes(self.slot_len, self.depth, self.num_owners, self.num_workers)
+            self.region_floats = sizes[srv.rank]
+            self.region = PeerRegion(srv.rank, srv.world_size, self.region_floats, dev, self.cp0,
+                                     name=self.ns + "/region", timeout_s=self.timeout_s, sizes=sizes)
+            self.blocks = ControlBlocks(srv.rank, srv.world_size, self.cp0, name=self.ns + "/ctl",
+                                        timeout_s=self.timeout_s, lanes=self.num_workers, owner_rank=srv.ps_rank)
+        elif not self.colocated:
             # data plane (after the layout is out: ps tasks join the process group once they have it)
+            self.plane = "p2p"
             if not dist.is_initialized():
                 host, port = srv.rendezvous_address()
                 backend = pick_backend(dev)
@@ -785,8 +854,16 @@ class AsyncPSStrategy:
                                    master_port=port, device=dev if backend == "nccl" else None)
             self.p2p = _P2P(self.my_rank)
             self.p2p.make_direction_groups()
+        if self.region is not None:
+            self._pulled = [0] * self.num_owners
+            self._sent_pulled = [[0] * self.num_owners for _ in range(self.depth)]
+            self._acked = [0] * self.num_owners
+            if dev.type == "cuda":
+                self._comm_stream = torch.cuda.Stream(device=dev)
+                self._ev_grad, self._ev_copied = torch.cuda.Event(), torch.cuda.Event()
         if self._service_thread is not None:
             self._service_thread.start()
+        if self.region is not None:
             import atexit
             atexit.register(self.close)       # the service thread must be gone before the interpreter tears down
         # chief initialises the owners, everybody else waits (chief-initialises / others-wait)
@@ -800,6 +877,30 @@ class AsyncPSStrategy:
         self.pull(model)
         if self.max_staleness is not None and self.region is None:
             self.cp0.clock_set_wait("workers", self.worker_index, 0, None)
+
+    def _choose_plane(self, dev, depth: int) -> dict:
+        """Chief, ps tasks as owners: the one-sided plane (peer regions + doorbell words) when every task runs on this
+        node and the ps tasks compute on the same kind of device as the workers; otherwise send/recv.
+        ``DTF_PS_DATA_PLANE=p2p|region`` overrides the choice."""
+        import os
+        import socket
+        want = os.environ.get("DTF_PS_DATA_PLANE", "")
+        if want not in ("", "p2p", "region"):
+            raise ValueError("DTF_PS_DATA_PLANE must be 'p2p' or 'region'")
+        if want == "p2p":
+            return {"plane": "p2p"}
+        here = "%s@%s" % (dev.type, socket.gethostname())
+        where = [self.cp0.get("%s/where/%d" % (self.ns, j), timeout_s=self.timeout_s).decode()
+                 for j in range(self.num_owners)]
+        hosts = {split_host(a) for job in ("ps", "worker") for a in self.server.cluster.job_tasks(job)}
+        one_node = all(w == here for w in where) and (len(hosts) == 1 or hosts <= _LOOPBACK)
+        if not one_node:
+            if want == "region":
+                raise RuntimeError("DTF_PS_DATA_PLANE=region needs every task on this node and on %s devices "
+                                   "(ps tasks: %s)" % (dev.type, where))
+            return {"plane": "p2p"}
+        nmax = max([_ranges_numel(r) for r in self.ranges] + [1])
+        return {"plane": "region", "device": dev.type, "stride": (nmax + 63) // 64 * 64, "depth": depth}
 
     def close(self, grace_s: float = 20.0):
         """End this worker's owner thread: wait for the chief's shutdown request to reach it, and if none comes
@@ -840,8 +941,7 @@ class AsyncPSStrategy:
         base = self.cp0.add(self.ns + "/init_done", 0)
         if self.region is not None:
             for j in range(self.num_owners):
-                b, e = self.ranges[j][0]
-                self.region.put(j, 0, store.flat[b:e])       # straight into the owner's variable shard
+                self._put_ranges(j, 0, store.flat)           # straight into the owner's variable plane
             self.region.sync()
             self._post("init", {"global_step": gs0})
         else:
@@ -899,11 +999,28 @@ class AsyncPSStrategy:
             self._spin(lambda: self._min_ack() >= self.clock, "the owners to apply this worker's gradients")
         self._account_acks()
 
+    def _put_ranges(self, j: int, off: int, flat: torch.Tensor):
+        """Owner ``j``'s elements of ``flat`` into its region at ``off``, packed in range order (current stream)."""
+        r = self.owner_rank(j)
+        for b, e in self.ranges[j]:
+            self.region.put(r, off, flat[b:e])
+            off += e - b
+
+    def _get_ranges(self, j: int, off: int, flat: torch.Tensor):
+        r = self.owner_rank(j)
+        for b, e in self.ranges[j]:
+            self.region.get(r, off, flat[b:e])
+            off += e - b
+
     def _region_pull(self, store):
-        """One-sided gets of every owner's variable shard straight into the flat buffer, on the current stream."""
+        """One-sided gets of every owner's variables straight into the flat buffer, on the current stream."""
         for j in range(self.num_owners):
             self._pulled[j] = self.blocks.version(j)
-        self.region.gather(0, store.flat)                # owner j's shard is flat[j*S:(j+1)*S]: one launch, all links
+        if self.colocated:
+            self.region.gather(0, store.flat)            # owner j's shard is flat[j*S:(j+1)*S]: one launch, all links
+        else:
+            for j in range(self.num_owners):             # ps tasks: the flat ranges of the variables each one owns
+                self._get_ranges(j, 0, store.flat)
         self.versions = list(self._pulled)
         self.last_global_step = self.blocks.global_step()
 
@@ -926,8 +1043,13 @@ class AsyncPSStrategy:
         else:
             ctx = _NullContext()
         with ctx:
-            # shard j of the gradient into this worker's slot of owner j's inbox: one launch, all links at once
-            self.region.scatter(3 * self.slot_len + (w * D + slot) * self.slot_len, store.flat_grad)
+            inbox = 3 * self.slot_len + (w * D + slot) * self.slot_len
+            if self.colocated:
+                # shard j of the gradient into this worker's slot of owner j's inbox: one launch, all links at once
+                self.region.scatter(inbox, store.flat_grad)
+            else:
+                for j in range(W):
+                    self._put_ranges(j, inbox, store.flat_grad)
             if on_gpu:
                 self._ev_copied.record(self._comm_stream)
             from .doorbell import ring
@@ -1047,9 +1169,13 @@ class AsyncPSStrategy:
         F = model.store.flat_len * 4
         out = {"worker_variables": F, "worker_gradients": F,
                "worker_slots": sum(t.numel() * 4 for t in model.store.slots.values())}
-        if self.region is not None:
+        if self.region is not None and self.colocated:
             S = self.slot_len * 4
             out.update({"owner_variables": S, "owner_slots": 2 * S, "owner_inbox": self.num_workers * self.depth * S,
+                        "region_total": self.region_floats * 4})
+        elif self.region is not None:
+            S = self.slot_len * 4        # held by each ps task, not by this worker
+            out.update({"ps_variables": S, "ps_slots": 2 * S, "ps_inbox": self.num_workers * self.depth * S,
                         "region_total": self.region_floats * 4})
         return out
 

@@ -66,12 +66,18 @@ class _PumpConfig(C.Structure):
 
 class ControlBlocks:
     """The control blocks of all owners, mapped into this process.  Construction is collective over the ``world``
-    ranks sharing ``name`` on the control plane ``cp`` (rank ``r`` creates owner ``r``'s block)."""
+    ranks sharing ``name`` on the control plane ``cp``: rank ``r`` creates one block with ``lanes`` lanes (default
+    ``world``: every rank is a worker and an owner).  ``owner_rank(j)`` is the rank whose block owner ``j`` uses
+    (default ``j``); with ps tasks the owners are the first ranks and the lanes count the workers only.  All methods
+    take owner and worker *indices*."""
 
-    def __init__(self, rank: int, world: int, cp, name: str = "co/ctl", timeout_s: float = 300.0):
+    def __init__(self, rank: int, world: int, cp, name: str = "co/ctl", timeout_s: float = 300.0,
+                 lanes: Optional[int] = None, owner_rank=None):
         from multiprocessing import resource_tracker, shared_memory
         self.rank, self.world = int(rank), int(world)
-        nbytes = (_HDR_WORDS + _LANE_WORDS * self.world) * 8
+        self.lanes = self.world if lanes is None else int(lanes)
+        self._blk = owner_rank if owner_rank is not None else (lambda j: j)
+        nbytes = (_HDR_WORDS + _LANE_WORDS * self.lanes) * 8
         seg = "dtfc_%s_%d" % (uuid.uuid4().hex[:12], self.rank)
         self._mine = shared_memory.SharedMemory(name=seg, create=True, size=nbytes)
         self._mine.buf[:nbytes] = bytes(nbytes)
@@ -94,44 +100,47 @@ class ControlBlocks:
 
     # ---- addresses for the native side
     def block_address(self, owner: int) -> int:
-        return self._base[owner]
+        return self._base[self._blk(owner)]
 
     def lane_address(self, owner: int, worker: int) -> int:
-        return self._base[owner] + (_HDR_WORDS + _LANE_WORDS * worker) * 8
+        return self._base[self._blk(owner)] + (_HDR_WORDS + _LANE_WORDS * worker) * 8
+
+    def _w(self, owner: int):
+        return self.words[self._blk(owner)]
 
     # ---- words
     def _lane(self, owner: int, worker: int) -> int:
         return _HDR_WORDS + _LANE_WORDS * worker
 
     def version(self, owner: int) -> int:
-        return int(self.words[owner][_VERSION])
+        return int(self._w(owner)[_VERSION])
 
     def global_step(self) -> int:
-        return int(self.words[0][_GSTEP])
+        return int(self._w(0)[_GSTEP])
 
     def ack(self, owner: int, worker: int) -> int:
-        return int(self.words[owner][self._lane(owner, worker) + _ACK])
+        return int(self._w(owner)[self._lane(owner, worker) + _ACK])
 
     def ack_version(self, owner: int, worker: int, slot: int) -> int:
-        return int(self.words[owner][self._lane(owner, worker) + _ACKV + slot])
+        return int(self._w(owner)[self._lane(owner, worker) + _ACKV + slot])
 
     def door(self, owner: int, worker: int) -> int:
-        return int(self.words[owner][self._lane(owner, worker) + _DOOR])
+        return int(self._w(owner)[self._lane(owner, worker) + _DOOR])
 
     def clock(self, worker: int) -> int:
-        return int(self.words[0][self._lane(0, worker) + _CLOCK])
+        return int(self._w(0)[self._lane(0, worker) + _CLOCK])
 
     def set_clock(self, worker: int, value: int):
-        self.words[0][self._lane(0, worker) + _CLOCK] = np.uint64(value)
+        self._w(0)[self._lane(0, worker) + _CLOCK] = np.uint64(value)
 
     def min_clock(self) -> int:
-        w = self.words[0]
-        return int(min(int(w[self._lane(0, i) + _CLOCK]) for i in range(self.world)))
+        w = self._w(0)
+        return int(min(int(w[self._lane(0, i) + _CLOCK]) for i in range(self.lanes)))
 
     def rebase_step(self, owner: int, global_step: int):
         """Owner (re-)initialised or restored with the cluster-wide step at ``global_step``: doors, acknowledgements
         and ``version`` stay monotonic (workers keep counting), only the step's base moves.  Pump paused."""
-        w = self.words[owner]
+        w = self._w(owner)
         version = int(w[_VERSION])
         w[_GSBASE] = np.uint64((int(global_step) - version) % (1 << 64))
         w[_GSTEP] = np.uint64(int(global_step))

@@ -40,6 +40,7 @@ def _k():
         nv.declare(lib, "dtf_mbox_local_ptr", [p], p)
         nv.declare(lib, "dtf_mbox_local_handle", [p, p])
         nv.declare(lib, "dtf_mbox_open_peer", [p, C.c_int, p])
+        nv.declare(lib, "dtf_mbox_set_peer_bytes", [p, C.c_int, ll])
         nv.declare(lib, "dtf_mbox_put", [p, C.c_int, ll, p, ll, p])
         nv.declare(lib, "dtf_mbox_get", [p, C.c_int, ll, p, ll, p])
         nv.declare(lib, "dtf_mbox_gather", [p, ll, p, ll, p])
@@ -65,8 +66,14 @@ class PeerRegion:
     exchanged through its key/value store; nobody returns before all regions are mapped).
     """
 
-    def __init__(self, rank: int, world: int, nfloats: int, device, cp, name: str = "mbox", timeout_s: float = 300.0):
-        self.rank, self.world, self.nfloats = int(rank), int(world), int(nfloats)
+    def __init__(self, rank: int, world: int, nfloats: int, device, cp, name: str = "mbox", timeout_s: float = 300.0,
+                 sizes: Optional[List[int]] = None):
+        # `sizes`: floats per rank when the regions differ (ps tasks hold variables, slots and inboxes; their workers
+        # hold nothing and allocate a token region); every rank passes the same list.  Default: `nfloats` everywhere.
+        self.sizes = [int(nfloats)] * int(world) if sizes is None else [max(int(s), 1) for s in sizes]
+        if len(self.sizes) != int(world):
+            raise ValueError("one region size per rank")
+        self.rank, self.world, self.nfloats = int(rank), int(world), self.sizes[int(rank)]
         self.device = torch.device(device)
         self.name = name
         self._h = None
@@ -103,6 +110,7 @@ class PeerRegion:
                 rc = lib.dtf_mbox_open_peer(self._h, r, C.create_string_buffer(raw, nb))
                 if rc:
                     raise RuntimeError("hipIpcOpenMemHandle of rank %d's region failed (%d)" % (r, rc))
+                lib.dtf_mbox_set_peer_bytes(self._h, r, self.sizes[r] * 4)
             self.local = torch.as_tensor(_DeviceMemory(lib.dtf_mbox_local_ptr(self._h), self.nfloats), device=self.device)
 
     # ------------------------------------------------------------------ CPU: POSIX shared memory
@@ -124,18 +132,19 @@ class PeerRegion:
             except Exception:
                 pass
             self._peers_shm.append(shm)
-            self._peer_views[r] = torch.frombuffer(shm.buf, dtype=torch.float32, count=self.nfloats)
+            self._peer_views[r] = torch.frombuffer(shm.buf, dtype=torch.float32, count=self.sizes[r])
 
     # ------------------------------------------------------------------ data movement
-    def _check(self, t: torch.Tensor, off: int):
+    def _check(self, t: torch.Tensor, off: int, peer: Optional[int] = None):
         if t.dtype != torch.float32 or not t.is_contiguous():
             raise ValueError("peer regions move contiguous float32 tensors")
-        if off < 0 or off + t.numel() > self.nfloats:
-            raise ValueError("range [%d, %d) outside the %d-float region" % (off, off + t.numel(), self.nfloats))
+        limit = min(self.sizes) if peer is None else self.sizes[peer]
+        if off < 0 or off + t.numel() > limit:
+            raise ValueError("range [%d, %d) outside the %d-float region" % (off, off + t.numel(), limit))
 
     def put(self, peer: int, dst_off: int, src: torch.Tensor):
         """``region[peer][dst_off : dst_off + src.numel()] = src`` (GPU: asynchronously, on the current stream)."""
-        self._check(src, dst_off)
+        self._check(src, dst_off, peer)
         if src.numel() == 0:
             return
         if self._h is not None:
@@ -148,7 +157,7 @@ class PeerRegion:
 
     def get(self, peer: int, src_off: int, dst: torch.Tensor):
         """``dst = region[peer][src_off : src_off + dst.numel()]``."""
-        self._check(dst, src_off)
+        self._check(dst, src_off, peer)
         if dst.numel() == 0:
             return
         if self._h is not None:

@@ -118,7 +118,9 @@ def test_launch_one_ps_eight_workers_async(tmp_path, colocated):
     assert sum("Training complete!" in v for v in logs.values()) == 8
     ck = latest_checkpoint(log_dir)
     step = int(ck.rsplit("-", 1)[1])
-    assert 160 <= step <= 160 + 8
+    # every worker checks the shared step before it starts a step, and may have one more gradient in flight per spare
+    # inbox slot (two slots here): the budget is overshot by at most workers * slots - 1
+    assert 160 <= step <= 160 + 8 * 2
     names = dict(list_variables(ck))
     assert names["dense_1/kernel"] == (64, 128) and "dense_3/kernel/Adam_1" in names
     with BundleReader(ck) as r:

@@ -47,12 +47,14 @@ def test_single_machine(tmp_path):
     assert ck is not None and ck.endswith("model.ckpt-150")
 
 
-@pytest.mark.parametrize("mode", ["async", "bounded", "sync"])
+@pytest.mark.parametrize("mode", ["async", "async-sendrecv", "bounded", "sync"])
 def test_one_ps_two_workers(tmp_path, mode):
     ps_port, w0, w1, rdv = _ports(4)
     hosts = {"PS_HOSTS": "127.0.0.1:%d" % ps_port, "WORKER_HOSTS": "127.0.0.1:%d,127.0.0.1:%d" % (w0, w1),
              "DTF_RENDEZVOUS_PORT": str(rdv)}
-    extra = {"async": [], "bounded": ["--max_staleness", "2"], "sync": ["--sync"]}[mode]
+    extra = {"async": [], "async-sendrecv": [], "bounded": ["--max_staleness", "2"], "sync": ["--sync"]}[mode]
+    if mode == "async-sendrecv":
+        hosts["DTF_PS_DATA_PLANE"] = "p2p"      # the plane of multi-node clusters (default here: peer regions)
     args = [sys.executable, SCRIPT, "--log_dir", str(tmp_path), "--last_step", "120", "--seed", "5"] + extra
     procs = {}
     logs = {}
