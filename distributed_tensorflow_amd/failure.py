@@ -2,9 +2,10 @@
 
 TensorFlow's distributed session notices a lost task when an RPC to it fails (``UnavailableError`` /
 ``AbortedError``) and ``MonitoredTrainingSession`` (/root/reference/example.py:189-192) then re-creates the
-session from the last checkpoint.  Here the data plane is a static RCCL / gloo process group, which cannot
+session from the last checkpoint.  Where the data plane is a static RCCL / gloo process group, it cannot
 re-admit a restarted member and - on RCCL - blocks inside a collective when a peer disappears.  Loss of a task
-is therefore detected out of band and answered by restarting the whole gang from the last checkpoint:
+is therefore detected out of band and answered by restarting the whole gang from the last checkpoint (the exception:
+workers of an elastic asynchronous cluster, see :func:`elastic_workers`):
 
 * every task runs a :class:`FailureDetector` thread that heartbeats to the control plane of the first
   parameter server (the chief in ps-less clusters) and asks it which members have gone silent;
@@ -40,8 +41,12 @@ def member_name(job: str, index: int) -> str:
 class FailureDetector:
     def __init__(self, address: Tuple[str, int], me: str, peers: Sequence[str], interval_s: float = 0.5,
                  max_age_s: float = 5.0, startup_grace_s: float = 120.0, abort_after_s: Optional[float] = None,
-                 on_abort: Optional[Callable[[List[str]], None]] = None):
+                 on_abort: Optional[Callable[[List[str]], None]] = None, tolerated: Sequence[str] = ()):
         self.address = address
+        # members whose silence is not the loss of the cluster: stateless workers of an elastic asynchronous cluster
+        # (their variables and optimizer state live on the parameter servers; the launcher restarts them one by one)
+        self.tolerated = set(tolerated)
+        self._absent: List[str] = []
         self.me = me
         self.peers = [p for p in peers if p != me]
         self.interval_s = interval_s
@@ -59,6 +64,11 @@ class FailureDetector:
     def lost(self) -> List[str]:
         with self._lock:
             return list(self._lost)
+
+    def absent(self) -> List[str]:
+        """Tolerated members that are silent right now."""
+        with self._lock:
+            return list(self._absent)
 
     def check(self):
         lost = self.lost()
@@ -115,8 +125,11 @@ class FailureDetector:
                 if self._stop.is_set():
                     return
                 lost = ["control plane at %s:%d" % self.address]
+            absent = [m for m in lost if m in self.tolerated]
+            lost = [m for m in lost if m not in self.tolerated]
             with self._lock:
                 self._lost = lost
+                self._absent = absent
             if not lost:
                 lost_since = None
                 continue
@@ -139,7 +152,17 @@ def detector_for_server(server, **kw) -> Optional[FailureDetector]:
         return None
     peers = [member_name("ps", j) for j in range(server.num_ps)] + \
             [member_name("worker", i) for i in range(server.num_workers)]
+    if elastic_workers(server) and "tolerated" not in kw:
+        kw["tolerated"] = [member_name("worker", i) for i in range(server.num_workers)]
     return FailureDetector(server.control_address(0), member_name(server.job_name, server.task_index), peers, **kw)
+
+
+def elastic_workers(server=None) -> bool:
+    """``DTF_ELASTIC_WORKERS=1`` in a cluster with parameter-server tasks: a worker that dies is restarted alone and
+    re-admitted by the running cluster (asynchronous mode on the one-sided data plane, where a worker holds no state
+    anybody else needs) - what ``MonitoredTrainingSession`` does for a TensorFlow worker whose variables live on the
+    ps tasks (/root/reference/example.py:136-139,189-192)."""
+    return os.environ.get("DTF_ELASTIC_WORKERS", "0") == "1" and (server is None or server.num_ps > 0)
 
 
 class HeartbeatHook(SessionRunHook):
@@ -168,6 +191,8 @@ class HeartbeatHook(SessionRunHook):
         strategy = getattr(getattr(session, "engine", None), "strategy", None)
         if self.detector is not None and strategy is not None and hasattr(strategy, "external_health_check"):
             strategy.external_health_check = self.detector.check
+            if hasattr(strategy, "external_absent"):
+                strategy.external_absent = self.detector.absent
 
     def before_run(self, run_context):
         if self.detector is not None:

@@ -9,6 +9,12 @@ crashed, or ended by its failure detector with status 75) the remaining tasks ar
 started again on fresh ports, up to ``--max_restarts`` times; the chief restores the latest checkpoint from the
 script's checkpoint directory, so training continues from the saved ``global_step``.
 
+With ``--elastic_workers`` (or ``DTF_ELASTIC_WORKERS=1``) a *worker* that ends abnormally is started again alone, on
+the same address, while the parameter servers and the other workers keep running: in the asynchronous mode on the
+one-sided data plane a worker holds no state anybody else needs, and its successor is re-admitted by the running
+cluster (``AsyncPSStrategy``) - TensorFlow's behaviour for a worker whose variables live on the ps tasks
+(/root/reference/example.py:136-139,189-192).  A lost ps task still restarts the gang.
+
 ``--run_dir`` receives one log per task and attempt plus ``pids.json`` (task name -> process id of the current
 attempt), rewritten at every (re)start.
 """
@@ -44,6 +50,9 @@ class Gang:
                  env: Optional[Dict[str, str]] = None):
         self.procs: Dict[Tuple[str, int], subprocess.Popen] = {}
         self.logs = []
+        self.attempt, self.run_dir, self.script_argv = attempt, run_dir, list(script_argv)
+        self.envs: Dict[Tuple[str, int], Dict[str, str]] = {}
+        self.task_restarts: Dict[str, int] = {}
         ports = free_ports(num_ps + num_workers + 1)
         ps_hosts = ",".join("127.0.0.1:%d" % p for p in ports[:num_ps])
         worker_hosts = ",".join("127.0.0.1:%d" % p for p in ports[num_ps:num_ps + num_workers])
@@ -55,17 +64,33 @@ class Gang:
             e = dict(base, JOB_NAME=job, TASK_INDEX=str(idx))
             if job == "worker":
                 e["LOCAL_RANK"] = str(idx)
-            out = None
-            if run_dir:
-                out = open(os.path.join(run_dir, "%s_%d.attempt%d.log" % (job, idx, attempt)), "w")
-                self.logs.append(out)
-            self.procs[(job, idx)] = subprocess.Popen([sys.executable] + script_argv, env=e, stdout=out,
-                                                      stderr=subprocess.STDOUT if out else None)
-        if run_dir:
-            tmp = os.path.join(run_dir, "pids.json.tmp")
+            self.envs[(job, idx)] = e
+            self._spawn((job, idx), "")
+        self._write_pids()
+
+    def _spawn(self, key: Tuple[str, int], suffix: str):
+        out = None
+        if self.run_dir:
+            out = open(os.path.join(self.run_dir, "%s_%d.attempt%d%s.log" % (key[0], key[1], self.attempt, suffix)), "w")
+            self.logs.append(out)
+        self.procs[key] = subprocess.Popen([sys.executable] + self.script_argv, env=self.envs[key], stdout=out,
+                                           stderr=subprocess.STDOUT if out else None)
+
+    def _write_pids(self):
+        if self.run_dir:
+            tmp = os.path.join(self.run_dir, "pids.json.tmp")
             with open(tmp, "w") as f:
-                json.dump({"attempt": attempt, "pids": {"%s:%d" % k: p.pid for k, p in self.procs.items()}}, f)
-            os.replace(tmp, os.path.join(run_dir, "pids.json"))
+                json.dump({"attempt": self.attempt, "pids": {"%s:%d" % k: p.pid for k, p in self.procs.items()},
+                           "task_restarts": self.task_restarts}, f)
+            os.replace(tmp, os.path.join(self.run_dir, "pids.json"))
+
+    def restart_task(self, key: Tuple[str, int]):
+        """Start one task again in place (same addresses, same attempt): an elastic worker's successor."""
+        name = "%s:%d" % key
+        n = self.task_restarts[name] = self.task_restarts.get(name, 0) + 1
+        self.envs[key]["DTF_TASK_RESTART_COUNT"] = str(n)
+        self._spawn(key, ".restart%d" % n)
+        self._write_pids()
 
     def failed(self) -> Optional[Tuple[Tuple[str, int], int]]:
         for k, p in self.procs.items():
@@ -98,10 +123,17 @@ class Gang:
 
 
 def run(script_argv: List[str], num_ps: int, num_workers: int, max_restarts: int = 3, run_dir: Optional[str] = None,
-        ps_exit_grace_s: float = 30.0, env: Optional[Dict[str, str]] = None, log=print) -> int:
+        ps_exit_grace_s: float = 30.0, env: Optional[Dict[str, str]] = None, log=print,
+        elastic_workers: Optional[bool] = None) -> int:
     if run_dir:
         os.makedirs(run_dir, exist_ok=True)
+    env = dict(os.environ if env is None else env)
+    if elastic_workers is None:
+        elastic_workers = env.get("DTF_ELASTIC_WORKERS", "0") == "1"
+    elastic_workers = bool(elastic_workers) and num_ps > 0
+    env["DTF_ELASTIC_WORKERS"] = "1" if elastic_workers else "0"
     attempt = 0
+    restarts = 0
     while True:
         gang = Gang(script_argv, num_ps, num_workers, attempt, run_dir, env)
         log("[launch] attempt %d: started %d ps + %d workers" % (attempt, num_ps, num_workers))
@@ -110,6 +142,14 @@ def run(script_argv: List[str], num_ps: int, num_workers: int, max_restarts: int
         try:
             while True:
                 failure = gang.failed()
+                if failure is not None and elastic_workers and failure[0][0] == "worker" and restarts < max_restarts:
+                    (job, idx), rc = failure
+                    restarts += 1
+                    log("[launch] task %s:%d ended with %s; restarting that task alone (restart %d of %d)"
+                        % (job, idx, "signal %d" % -rc if rc < 0 else "status %d" % rc, restarts, max_restarts))
+                    gang.restart_task((job, idx))
+                    failure = None
+                    continue
                 if failure is not None or gang.all_done():
                     break
                 if gang.workers_done():
@@ -125,12 +165,13 @@ def run(script_argv: List[str], num_ps: int, num_workers: int, max_restarts: int
             return 0
         (job, idx), rc = failure
         why = "signal %d" % -rc if rc < 0 else "status %d" % rc
-        if attempt >= max_restarts:
+        if restarts >= max_restarts:
             log("[launch] task %s:%d ended with %s; no restarts left" % (job, idx, why))
             return rc if rc > 0 else 1
         attempt += 1
+        restarts += 1
         log("[launch] task %s:%d ended with %s; restarting the cluster (restart %d of %d)"
-            % (job, idx, why, attempt, max_restarts))
+            % (job, idx, why, restarts, max_restarts))
 
 
 def main(argv=None) -> int:
@@ -140,10 +181,13 @@ def main(argv=None) -> int:
     ap.add_argument("--num_workers", type=int, default=2)
     ap.add_argument("--max_restarts", type=int, default=3)
     ap.add_argument("--run_dir", default=None, help="directory for per-task logs and pids.json")
+    ap.add_argument("--elastic_workers", action="store_true",
+                    help="restart a failed worker alone and let the running cluster re-admit it (asynchronous mode)")
     ap.add_argument("script", help="training script; everything after it is passed to the script")
     ap.add_argument("script_args", nargs=argparse.REMAINDER)
     a = ap.parse_args(argv)
-    return run([a.script] + a.script_args, a.num_ps, a.num_workers, a.max_restarts, a.run_dir)
+    return run([a.script] + a.script_args, a.num_ps, a.num_workers, a.max_restarts, a.run_dir,
+               elastic_workers=True if a.elastic_workers else None)
 
 
 if __name__ == "__main__":

@@ -520,6 +520,13 @@ class ParameterServerService:
                 self._reply(w, st, self.owner_index == 0, seq)
                 if self.n:
                     self._send_params(w, wr)
+            elif op == "rejoin":
+                # a restarted worker takes over lane `w`: nothing is in flight from its predecessor once the pump has
+                # drained, so door, acknowledgement and the pump's own count can all move to the agreed number
+                self._quiesce()
+                self.blocks.set_lane(self.owner_index, w, int(req["seq"]))
+                self._release(resync=True)
+                self.cp0.add("%s/rejoin_done/%d" % (self.ns, w), 1)
             elif op == "pull":
                 self._reply(w, 0, False, seq)
                 if self.n:
@@ -677,6 +684,8 @@ class AsyncPSStrategy:
         self.region = None
         self.p2p = None
         self.plane = None             # "region" (peer regions + doorbell words) or "p2p" (send/recv), set by prepare
+        self.elastic = False          # DTF_ELASTIC_WORKERS=1: workers may die and be re-admitted (ps tasks own all state)
+        self._rejoined = False        # this process replaced a worker that died
         self.blocks = None            # doorbell.ControlBlocks: the owners' words (region plane)
         self.depth = 1                # inbox slots per (owner, worker): gradients a worker may have outstanding
         self._pulled: List[int] = []  # owner versions seen at the last pull
@@ -817,12 +826,21 @@ class AsyncPSStrategy:
             self._service_thread = threading.Thread(target=self._run_service, name="dtf-owner-%d" % self.worker_index,
                                                     daemon=True)
             plane = {"plane": "region", "stride": S, "depth": self.depth}
-        elif srv.is_chief:
-            plane = self._choose_plane(dev, depth)
-            self.cp0.set_json(self.ns + "/plane", plane)
         else:
-            plane = self.cp0.get_json(self.ns + "/plane", timeout_s=self.timeout_s)
-        if srv.is_chief:
+            # elastic workers: the second process to announce itself as worker i is its restarted successor, and
+            # joins the running cluster instead of taking part in its start-up
+            from ..failure import elastic_workers
+            self.elastic = elastic_workers(srv)
+            self._rejoined = self.elastic and self.cp0.add("%s/joined/%d" % (self.ns, self.worker_index), 1) > 1
+            if srv.is_chief and not self._rejoined:
+                plane = self._choose_plane(dev, depth)
+                self.cp0.set_json(self.ns + "/plane", plane)
+            else:
+                plane = self.cp0.get_json(self.ns + "/plane", timeout_s=self.timeout_s)
+            if self.elastic and plane["plane"] != "region":
+                raise RuntimeError("DTF_ELASTIC_WORKERS=1 needs the one-sided data plane (every task on one node, one "
+                                   "kind of device): a send/recv process group cannot re-admit a restarted worker")
+        if srv.is_chief and not self._rejoined:
             layout = {"ranges": self.ranges, "optimizer": opt_desc, "flat_len": store.flat_len,
                       "variables": self.var_table}
             layout.update(plane)
@@ -841,9 +859,11 @@ class AsyncPSStrategy:
             sizes = region_sizes(self.slot_len, self.depth, self.num_owners, self.num_workers)
             self.region_floats = sizes[srv.rank]
             self.region = PeerRegion(srv.rank, srv.world_size, self.region_floats, dev, self.cp0,
-                                     name=self.ns + "/region", timeout_s=self.timeout_s, sizes=sizes)
+                                     name=self.ns + "/region", timeout_s=self.timeout_s, sizes=sizes,
+                                     rejoin=self._rejoined)
             self.blocks = ControlBlocks(srv.rank, srv.world_size, self.cp0, name=self.ns + "/ctl",
-                                        timeout_s=self.timeout_s, lanes=self.num_workers, owner_rank=srv.ps_rank)
+                                        timeout_s=self.timeout_s, lanes=self.num_workers, owner_rank=srv.ps_rank,
+                                        rejoin=self._rejoined)
         elif not self.colocated:
             # data plane (after the layout is out: ps tasks join the process group once they have it)
             self.plane = "p2p"
@@ -868,7 +888,10 @@ class AsyncPSStrategy:
             atexit.register(self.close)       # the service thread must be gone before the interpreter tears down
         # chief initialises the owners, everybody else waits (chief-initialises / others-wait)
         self.versions = [0] * self.num_owners
-        if srv.is_chief:
+        if self._rejoined:
+            self.cp0.get(self.ns + "/initialized", timeout_s=self.timeout_s)
+            self._rejoin_owners()
+        elif srv.is_chief:
             self._wait_counter(self.ns + "/ready", self.num_owners)
             self._init_owners(store, int(store.global_step.item()))
             self.cp0.set(self.ns + "/initialized", b"1")
@@ -877,6 +900,24 @@ class AsyncPSStrategy:
         self.pull(model)
         if self.max_staleness is not None and self.region is None:
             self.cp0.clock_set_wait("workers", self.worker_index, 0, None)
+
+    def _rejoin_owners(self):
+        """Restarted worker: continue this worker's lanes.  Its predecessor may have died between two owners' doorbells,
+        so every owner is told the one gradient number to continue from - nothing rung below it is waited for, and a
+        gradient that was complete in some inboxes only is dropped there.  The number also serves as this worker's
+        clock, so it starts no further back than the slowest running worker (it must not hold the others to a
+        staleness bound measured against steps its predecessor never made)."""
+        w, b = self.worker_index, self.blocks
+        seq = max(b.door(j, w) for j in range(self.num_owners))
+        running = [c for c in (b.clock(i) for i in range(self.num_workers) if i != w) if c < (1 << 59)]
+        if running:
+            seq = max(seq, min(running))
+        base = self.cp0.add("%s/rejoin_done/%d" % (self.ns, w), 0)
+        self._post("rejoin", {"seq": seq})
+        self._wait_counter("%s/rejoin_done/%d" % (self.ns, w), base + self.num_owners)
+        b.set_clock(w, seq)
+        self.clock = seq
+        self._acked = [seq] * self.num_owners
 
     def _choose_plane(self, dev, depth: int) -> dict:
         """Chief, ps tasks as owners: the one-sided plane (peer regions + doorbell words) when every task runs on this
@@ -1066,8 +1107,8 @@ class AsyncPSStrategy:
         if self.max_staleness is not None:
             # stale-synchronous bound over the workers' clocks (completed pushes), read from owner 0's block
             s = self.max_staleness
-            if self.clock - self.blocks.min_clock() > s:
-                self.wait_seconds += self._spin(lambda: self.clock - self.blocks.min_clock() <= s,
+            if self.clock - self.min_clock() > s:
+                self.wait_seconds += self._spin(lambda: self.clock - self.min_clock() <= s,
                                                 "the slowest worker (staleness bound)")
         self._region_pull(store)
         if self.last_global_step:
@@ -1076,8 +1117,18 @@ class AsyncPSStrategy:
     def min_clock(self) -> int:
         """The slowest worker's clock (pushes completed), as the staleness bound sees it."""
         if self.blocks is not None:
-            return self.blocks.min_clock()
+            return self.blocks.min_clock(skip=self._absent_workers())
         return self.cp0.clock_min("workers")
+
+    #: set by the session's heartbeat hook: the tolerated members (elastic workers) that are silent right now
+    external_absent = None
+
+    def _absent_workers(self):
+        """Indices of workers the failure detector reports absent: a dead worker's clock stands still and must not
+        hold the others to the staleness bound until its successor has rejoined."""
+        if not self.elastic or self.external_absent is None:
+            return ()
+        return tuple(int(m.split(":")[1]) for m in self.external_absent() if m.startswith("worker:"))
 
     # -- data movement: ps tasks (torch.distributed send/recv + folded control traffic)
     def _receive_params(self, store):
@@ -1186,6 +1237,12 @@ class AsyncPSStrategy:
         store = model.store
         first = not getattr(self, "_published", False)
         self._published = True
+        if self._rejoined:
+            # the owners hold the live state (a chief that comes back must not roll them back to a checkpoint)
+            model._restored_from = None
+            self.pull(model)
+            store.global_step.fill_(self.global_step())
+            return
         if is_chief:
             prefix = getattr(model, "_restored_from", None)
             gs = int(store.global_step.item())

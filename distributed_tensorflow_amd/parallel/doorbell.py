@@ -72,7 +72,7 @@ class ControlBlocks:
     take owner and worker *indices*."""
 
     def __init__(self, rank: int, world: int, cp, name: str = "co/ctl", timeout_s: float = 300.0,
-                 lanes: Optional[int] = None, owner_rank=None):
+                 lanes: Optional[int] = None, owner_rank=None, rejoin: bool = False):
         from multiprocessing import resource_tracker, shared_memory
         self.rank, self.world = int(rank), int(world)
         self.lanes = self.world if lanes is None else int(lanes)
@@ -96,7 +96,8 @@ class ControlBlocks:
             self._shms[r] = shm
         self.words = [np.frombuffer(s.buf, dtype=np.uint64, count=nbytes // 8) for s in self._shms]
         self._base = [C.addressof(C.c_char.from_buffer(s.buf)) for s in self._shms]
-        cp.barrier("%s/mapped" % name, self.world, timeout_s=timeout_s)
+        if not rejoin:      # a restarted process maps the blocks of ranks that have been running for a while
+            cp.barrier("%s/mapped" % name, self.world, timeout_s=timeout_s)
 
     # ---- addresses for the native side
     def block_address(self, owner: int) -> int:
@@ -133,9 +134,18 @@ class ControlBlocks:
     def set_clock(self, worker: int, value: int):
         self._w(0)[self._lane(0, worker) + _CLOCK] = np.uint64(value)
 
-    def min_clock(self) -> int:
+    def min_clock(self, skip=()) -> int:
+        """The slowest worker's clock; ``skip``: worker indices to leave out (tasks known to be absent)."""
         w = self._w(0)
-        return int(min(int(w[self._lane(0, i) + _CLOCK]) for i in range(self.lanes)))
+        clocks = [int(w[self._lane(0, i) + _CLOCK]) for i in range(self.lanes) if i not in skip]
+        return min(clocks) if clocks else 1 << 60
+
+    def set_lane(self, owner: int, worker: int, seq: int):
+        """Owner side, pump paused: a restarted worker continues its lane at gradient number ``seq`` - whatever its
+        predecessor rang but never completed is dropped."""
+        w = self._w(owner)
+        w[self._lane(owner, worker) + _DOOR] = np.uint64(seq)
+        w[self._lane(owner, worker) + _ACK] = np.uint64(seq)
 
     def rebase_step(self, owner: int, global_step: int):
         """Owner (re-)initialised or restored with the cluster-wide step at ``global_step``: doors, acknowledgements

@@ -67,7 +67,7 @@ class PeerRegion:
     """
 
     def __init__(self, rank: int, world: int, nfloats: int, device, cp, name: str = "mbox", timeout_s: float = 300.0,
-                 sizes: Optional[List[int]] = None):
+                 sizes: Optional[List[int]] = None, rejoin: bool = False):
         # `sizes`: floats per rank when the regions differ (ps tasks hold variables, slots and inboxes; their workers
         # hold nothing and allocate a token region); every rank passes the same list.  Default: `nfloats` everywhere.
         self.sizes = [int(nfloats)] * int(world) if sizes is None else [max(int(s), 1) for s in sizes]
@@ -87,7 +87,10 @@ class PeerRegion:
             self._init_gpu(cp, timeout_s)
         else:
             self._init_cpu(cp, timeout_s)
-        cp.barrier("%s/mapped" % name, self.world, timeout_s=timeout_s)
+        # `rejoin`: a restarted process takes the place of a rank whose peers mapped everything long ago - it publishes
+        # its new handle, maps the others from theirs and waits for nobody
+        if not rejoin:
+            cp.barrier("%s/mapped" % name, self.world, timeout_s=timeout_s)
 
     # ------------------------------------------------------------------ GPU: hipIpc
     def _init_gpu(self, cp, timeout_s):

@@ -152,3 +152,58 @@ def test_example2_cluster_surfaces_a_lost_worker(tmp_path):
                 p.kill()
         for f in logs.values():
             f.close()
+
+
+@pytest.mark.parametrize("victim,staleness", [("worker:1", "-1"), ("worker:0", "3")])
+def test_elastic_worker_is_restarted_alone_and_readmitted(tmp_path, victim, staleness):
+    """``launch --elastic_workers``: asynchronous training with the variables on a ps task (one-sided data plane).  A
+    killed worker - the chief included - is started again alone; the ps task and the other worker keep their processes
+    and keep training; the successor continues the dead worker's lanes, does not roll the owners back to a checkpoint,
+    and the cluster reaches its step budget.  With a staleness bound the dead worker's clock does not hold the
+    survivor back."""
+    elastic_run(tmp_path, victim, staleness, _env({}))
+
+
+def elastic_run(tmp_path, victim, staleness, base_env):
+    log_dir, run_dir = str(tmp_path / "logs"), str(tmp_path / "run")
+    last_step = 9000
+    env = dict(base_env, DTF_HEARTBEAT_MAX_AGE_SECS="1.5", DTF_HEARTBEAT_ABORT_SECS="2", DTF_HEARTBEAT_SECS="0.2",
+               PYTHONPATH=ROOT)
+    launcher = subprocess.Popen(
+        [sys.executable, "-m", "distributed_tensorflow_amd.launch", "--num_ps", "1", "--num_workers", "2",
+         "--max_restarts", "2", "--elastic_workers", "--run_dir", run_dir, SCRIPT, "--log_dir", log_dir, "--seed", "2",
+         "--last_step", str(last_step), "--save_checkpoint_secs", "0.3", "--max_staleness", staleness],
+        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, cwd=ROOT)
+    try:
+        def progressed():
+            ck = latest_checkpoint(log_dir) if os.path.isdir(log_dir) else None
+            return ck is not None and int(ck.rsplit("-", 1)[1]) >= 300
+        assert _wait(progressed, timeout=180), "no checkpoint from the cluster"
+        assert launcher.poll() is None, launcher.stdout.read()[-3000:]
+        with open(os.path.join(run_dir, "pids.json")) as f:
+            before = json.load(f)
+        killed_at = int(latest_checkpoint(log_dir).rsplit("-", 1)[1])
+        assert killed_at < last_step, "run finished before the fault could be injected"
+        os.kill(before["pids"][victim], signal.SIGKILL)
+        out, _ = launcher.communicate(timeout=300)
+    finally:
+        if launcher.poll() is None:
+            launcher.kill()
+    logs = {f: open(os.path.join(run_dir, f)).read() for f in sorted(os.listdir(run_dir)) if f.endswith(".log")}
+    report = out[-2000:] + "\n" + "\n".join("== %s\n%s" % (k, v[-1500:]) for k, v in logs.items())
+    assert launcher.returncode == 0, report
+    assert "restarting that task alone (restart 1 of 2)" in out and "restarting the cluster" not in out, report
+    with open(os.path.join(run_dir, "pids.json")) as f:
+        after = json.load(f)
+    assert after["attempt"] == 0 and after["task_restarts"] == {victim: 1}
+    survivors = [k for k in before["pids"] if k != victim]
+    assert all(after["pids"][k] == before["pids"][k] for k in survivors)          # nobody else was restarted
+    assert after["pids"][victim] != before["pids"][victim]
+    job, idx = victim.split(":")
+    successor = logs["%s_%s.attempt0.restart1.log" % (job, idx)]
+    other = logs["worker_%d.attempt0.log" % (1 - int(idx))]
+    assert "Training complete!" in successor and "Training complete!" in other, report
+    assert "ClusterLostError" not in other
+    ck = latest_checkpoint(log_dir)
+    step = int(ck.rsplit("-", 1)[1])
+    assert last_step <= step <= last_step + 6, report     # the shared step went on counting: no rollback, no fresh run

@@ -74,6 +74,13 @@ def test_one_ps_two_workers_on_one_gpu(tmp_path, mode):
     assert ck is not None and 200 <= int(ck.rsplit("-", 1)[1]) <= 204
 
 
+def test_elastic_worker_is_readmitted_on_the_gpu(tmp_path):
+    """1 ps + 2 workers on the one GPU, variables in the ps task's hipIpc-mapped region: a killed worker is restarted
+    alone, maps the owner's region again and continues its doorbell lane while the others keep training."""
+    from .test_failure import elastic_run
+    elastic_run(tmp_path, "worker:1", "3", _env({"HSA_ENABLE_IPC_MODE_LEGACY": "0"}))
+
+
 @pytest.mark.parametrize("allreduce", ["rccl", "p2p"])
 def test_bench_two_ranks_share_the_gpu(allreduce):
     """bench.py launched exactly as the multi-GPU driver launches it (torch.distributed.run, 2 ranks); "rccl" is the
