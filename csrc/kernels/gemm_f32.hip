@@ -1307,6 +1307,8 @@ __global__ __launch_bounds__(256) void reduce_fwd_slabs_kernel(const float* __re
 // K splits of the forward product (1 = no split).  Only products that cannot fill the chip with output tiles split.
 DTF_API int dtf_dense_fwd_splits(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K < 1024 || N % 4 != 0 || N <= 32) return 1;
+    static const int forced = getenv("DTF_FWD_SPLITS") ? atoi(getenv("DTF_FWD_SPLITS")) : 0;   // tuning aid
+    if (forced > 0) return forced;
     const long long tiles = (long long)((M + 63) / 64) * ((N + 63) / 64);     // the smallest tile gives the most blocks
     if (tiles >= 256) return 1;
     long long s = 512 / tiles;

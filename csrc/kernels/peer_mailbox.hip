@@ -73,7 +73,102 @@ int launch_peer_shards(Mailbox* m, bool gather, long long off, void* local, long
     return 0;
 }
 
+// A list of ranges in ONE launch: range r connects `n16` 16-byte units at byte `local_off` of a local buffer with byte
+// `remote_base + remote_off` of rank `peer`'s region.  What a worker of a cluster whose ps tasks own whole variables
+// needs every step: the flat ranges of every owner's variables (round-robin placement interleaves them), pushed into
+// the owners' inbox slots or pulled from their variable planes, all owners and all ranges at once instead of one
+// runtime copy each.
+struct RangeDesc {
+    int peer, pad;
+    long long remote_off, local_off, n16;
+};
+
+struct RangeTable {
+    RangeDesc* dev = nullptr;
+    int count = 0;
+    long long max_n16 = 0;
+    long long local_end = 0;                    // bytes of the local buffer the ranges reach
+    long long remote_end[MBOX_MAX_RANKS] = {};  // bytes of each peer's region the ranges reach (before remote_base)
+};
+
+template <bool GATHER>
+__global__ __launch_bounds__(256) void peer_ranges_kernel(PeerTable peers, const RangeDesc* __restrict__ ranges, char* local,
+                                                          long long remote_base) {
+    const RangeDesc r = ranges[blockIdx.y];
+    f32x4* remote = reinterpret_cast<f32x4*>(peers.ptr[r.peer] + remote_base + r.remote_off);
+    f32x4* mine = reinterpret_cast<f32x4*>(local + r.local_off);
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < r.n16; i += stride) {
+        if (GATHER) mine[i] = __builtin_nontemporal_load(remote + i);
+        else __builtin_nontemporal_store(mine[i], remote + i);
+    }
+    if (!GATHER) __threadfence_system();
+}
+
 }  // namespace
+
+// Validates `count` ranges (host array of {int peer, int pad, long long remote_off, local_off, n16}; offsets in bytes,
+// multiples of 16) against the regions' sizes and uploads them.  Null if any range is malformed.
+DTF_API void* dtf_mbox_ranges_create(void* h, const void* host_descs, int count) {
+    auto* m = static_cast<Mailbox*>(h);
+    if (count < 1 || count > 65535 || !host_descs) return nullptr;
+    const RangeDesc* d = static_cast<const RangeDesc*>(host_descs);
+    auto* t = new RangeTable();
+    t->count = count;
+    for (int i = 0; i < count; ++i) {
+        const RangeDesc& r = d[i];
+        if (r.peer < 0 || r.peer >= m->world || !m->peer[r.peer] || r.n16 < 0 || r.remote_off < 0 || r.local_off < 0 ||
+            (r.remote_off & 15) || (r.local_off & 15) || (size_t)(r.remote_off + r.n16 * 16) > m->size[r.peer]) {
+            delete t;
+            return nullptr;
+        }
+        if (r.n16 > t->max_n16) t->max_n16 = r.n16;
+        if (r.local_off + r.n16 * 16 > t->local_end) t->local_end = r.local_off + r.n16 * 16;
+        if (r.remote_off + r.n16 * 16 > t->remote_end[r.peer]) t->remote_end[r.peer] = r.remote_off + r.n16 * 16;
+    }
+    if (hipMalloc(&t->dev, sizeof(RangeDesc) * (size_t)count) != hipSuccess ||
+        hipMemcpy(t->dev, d, sizeof(RangeDesc) * (size_t)count, hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipGetLastError();
+        if (t->dev) (void)hipFree(t->dev);
+        delete t;
+        return nullptr;
+    }
+    return t;
+}
+
+DTF_API void dtf_mbox_ranges_destroy(void* table) {
+    auto* t = static_cast<RangeTable*>(table);
+    if (!t) return;
+    if (t->dev) (void)hipFree(t->dev);
+    delete t;
+}
+
+// Runs the table: gather != 0 copies remote -> local, else local -> remote.  `remote_base` (bytes, multiple of 16)
+// is added to every range's remote offset (which inbox slot; 0 for the variable plane); `local` holds at least
+// `local_bytes` bytes.
+DTF_API int dtf_mbox_ranges_run(void* h, void* table, int gather, long long remote_base, void* local, long long local_bytes,
+                                hipStream_t stream) {
+    auto* m = static_cast<Mailbox*>(h);
+    auto* t = static_cast<RangeTable*>(table);
+    if (!t || !t->dev) return -2;
+    if (remote_base < 0 || (remote_base & 15) || (reinterpret_cast<uintptr_t>(local) & 15) || t->local_end > local_bytes) return -3;
+    PeerTable pt;
+    for (int r = 0; r < m->world; ++r) {
+        if (t->remote_end[r] && (!m->peer[r] || (size_t)(remote_base + t->remote_end[r]) > m->size[r])) return -3;
+        pt.ptr[r] = static_cast<char*>(m->peer[r]);
+    }
+    if (t->max_n16 == 0) return 0;
+    long long bx = (t->max_n16 + 255) / 256;
+    const long long cap = 2048 / t->count > 1 ? 2048 / t->count : 1;
+    if (bx > cap) bx = cap;
+    const dim3 grid((unsigned)bx, (unsigned)t->count);
+    if (gather)
+        hipLaunchKernelGGL(peer_ranges_kernel<true>, grid, dim3(256), 0, stream, pt, t->dev, static_cast<char*>(local), remote_base);
+    else
+        hipLaunchKernelGGL(peer_ranges_kernel<false>, grid, dim3(256), 0, stream, pt, t->dev, static_cast<char*>(local), remote_base);
+    DTF_CHECK_LAUNCH();
+    return 0;
+}
 
 // dst[j * shard_bytes ...] = region of rank j at byte offset `src_off`, for every rank j, in ONE launch on `stream`.
 DTF_API int dtf_mbox_gather(void* h, long long src_off, void* dst, long long shard_bytes, hipStream_t stream) {

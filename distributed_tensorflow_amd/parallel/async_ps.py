@@ -686,6 +686,7 @@ class AsyncPSStrategy:
         self.plane = None             # "region" (peer regions + doorbell words) or "p2p" (send/recv), set by prepare
         self.elastic = False          # DTF_ELASTIC_WORKERS=1: workers may die and be re-admitted (ps tasks own all state)
         self._rejoined = False        # this process replaced a worker that died
+        self._range_table = None      # peer_region.RangeTable of the owners' flat ranges (ps tasks on the region plane)
         self.blocks = None            # doorbell.ControlBlocks: the owners' words (region plane)
         self.depth = 1                # inbox slots per (owner, worker): gradients a worker may have outstanding
         self._pulled: List[int] = []  # owner versions seen at the last pull
@@ -981,8 +982,12 @@ class AsyncPSStrategy:
         """Chief: ship the initial values to every owner, reset their slots and the shared step."""
         base = self.cp0.add(self.ns + "/init_done", 0)
         if self.region is not None:
-            for j in range(self.num_owners):
-                self._put_ranges(j, 0, store.flat)           # straight into the owner's variable plane
+            if self.colocated:
+                for j in range(self.num_owners):
+                    b, e = self.ranges[j][0]
+                    self.region.put(j, 0, store.flat[b:e])   # straight into the owner's variable shard
+            else:
+                self.region.move_ranges(self._owner_ranges_table(), False, 0, store.flat)
             self.region.sync()
             self._post("init", {"global_step": gs0})
         else:
@@ -1040,18 +1045,18 @@ class AsyncPSStrategy:
             self._spin(lambda: self._min_ack() >= self.clock, "the owners to apply this worker's gradients")
         self._account_acks()
 
-    def _put_ranges(self, j: int, off: int, flat: torch.Tensor):
-        """Owner ``j``'s elements of ``flat`` into its region at ``off``, packed in range order (current stream)."""
-        r = self.owner_rank(j)
-        for b, e in self.ranges[j]:
-            self.region.put(r, off, flat[b:e])
-            off += e - b
-
-    def _get_ranges(self, j: int, off: int, flat: torch.Tensor):
-        r = self.owner_rank(j)
-        for b, e in self.ranges[j]:
-            self.region.get(r, off, flat[b:e])
-            off += e - b
+    def _owner_ranges_table(self):
+        """ps tasks as owners: every flat range of every owner's variables against its place in the owner's packed
+        shard - one table, so that a push or a pull is one launch whatever the placement interleaves."""
+        if self._range_table is None:
+            descs = []
+            for j in range(self.num_owners):
+                pos = 0
+                for b, e in self.ranges[j]:
+                    descs.append((self.owner_rank(j), pos, b, e - b))
+                    pos += e - b
+            self._range_table = self.region.make_ranges(descs)
+        return self._range_table
 
     def _region_pull(self, store):
         """One-sided gets of every owner's variables straight into the flat buffer, on the current stream."""
@@ -1060,8 +1065,8 @@ class AsyncPSStrategy:
         if self.colocated:
             self.region.gather(0, store.flat)            # owner j's shard is flat[j*S:(j+1)*S]: one launch, all links
         else:
-            for j in range(self.num_owners):             # ps tasks: the flat ranges of the variables each one owns
-                self._get_ranges(j, 0, store.flat)
+            # ps tasks: the flat ranges of the variables each one owns, all owners in one launch
+            self.region.move_ranges(self._owner_ranges_table(), True, 0, store.flat)
         self.versions = list(self._pulled)
         self.last_global_step = self.blocks.global_step()
 
@@ -1089,8 +1094,7 @@ class AsyncPSStrategy:
                 # shard j of the gradient into this worker's slot of owner j's inbox: one launch, all links at once
                 self.region.scatter(inbox, store.flat_grad)
             else:
-                for j in range(W):
-                    self._put_ranges(j, inbox, store.flat_grad)
+                self.region.move_ranges(self._owner_ranges_table(), False, inbox, store.flat_grad)
             if on_gpu:
                 self._ev_copied.record(self._comm_stream)
             from .doorbell import ring

@@ -31,6 +31,7 @@ _HDR_WORDS = 16
 _VERSION, _GSTEP, _GSBASE = 0, 1, 2
 
 _lib = None
+_CREATED_HERE = set()       # shared-memory segments this process created (several ranks as threads: tests)
 
 
 def _k():
@@ -79,6 +80,7 @@ class ControlBlocks:
         self._blk = owner_rank if owner_rank is not None else (lambda j: j)
         nbytes = (_HDR_WORDS + _LANE_WORDS * self.lanes) * 8
         seg = "dtfc_%s_%d" % (uuid.uuid4().hex[:12], self.rank)
+        _CREATED_HERE.add(seg)
         self._mine = shared_memory.SharedMemory(name=seg, create=True, size=nbytes)
         self._mine.buf[:nbytes] = bytes(nbytes)
         cp.set("%s/handle/%d" % (name, self.rank), seg.encode())
@@ -89,10 +91,11 @@ class ControlBlocks:
                 continue
             peer = cp.get("%s/handle/%d" % (name, r), timeout_s=timeout_s).decode()
             shm = shared_memory.SharedMemory(name=peer)
-            try:        # the attaching process must not unlink the creator's segment when it exits
-                resource_tracker.unregister(shm._name, "shared_memory")
-            except Exception:
-                pass
+            if shm._name.lstrip("/") not in _CREATED_HERE:
+                try:    # the attaching process must not unlink the creator's segment when it exits
+                    resource_tracker.unregister(shm._name, "shared_memory")
+                except Exception:
+                    pass
             self._shms[r] = shm
         self.words = [np.frombuffer(s.buf, dtype=np.uint64, count=nbytes // 8) for s in self._shms]
         self._base = [C.addressof(C.c_char.from_buffer(s.buf)) for s in self._shms]

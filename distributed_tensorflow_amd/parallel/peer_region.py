@@ -27,6 +27,7 @@ import torch
 from ..ops import _native as nv
 
 _lib = None
+_CREATED_HERE = set()       # shared-memory segments this process created (several ranks as threads: tests)
 
 
 def _k():
@@ -45,10 +46,27 @@ def _k():
         nv.declare(lib, "dtf_mbox_get", [p, C.c_int, ll, p, ll, p])
         nv.declare(lib, "dtf_mbox_gather", [p, ll, p, ll, p])
         nv.declare(lib, "dtf_mbox_scatter", [p, ll, p, ll, p])
+        nv.declare(lib, "dtf_mbox_ranges_create", [p, p, C.c_int], p)
+        nv.declare(lib, "dtf_mbox_ranges_destroy", [p], None)
+        nv.declare(lib, "dtf_mbox_ranges_run", [p, p, C.c_int, ll, p, ll, p])
         nv.declare(lib, "dtf_mbox_sync", [p])
         nv.declare(lib, "dtf_mbox_destroy", [p], None)
         _lib = lib
     return _lib
+
+
+class _RangeDesc(C.Structure):
+    _fields_ = [("peer", C.c_int), ("pad", C.c_int), ("remote_off", C.c_longlong), ("local_off", C.c_longlong),
+                ("n16", C.c_longlong)]
+
+
+class RangeTable:
+    """A fixed list of ``(peer, remote_off, local_off, n)`` ranges (floats) between a local buffer and the peers'
+    regions, moved by one kernel launch (``PeerRegion.move_ranges``)."""
+
+    def __init__(self, ranges, handle=None):
+        self.ranges = [tuple(int(v) for v in r) for r in ranges]
+        self.handle = handle
 
 
 class _DeviceMemory:
@@ -80,6 +98,7 @@ class PeerRegion:
         self._shm = None
         self._peers_shm: List = []
         self._peer_views: List[Optional[torch.Tensor]] = [None] * self.world
+        self._tables: List[RangeTable] = []
         # DTF_PEER_KERNELS=0: gather / scatter fall back to one runtime copy per peer (hipMemcpyAsync) instead of the
         # kernels that load from / store to peer-mapped memory directly
         self._kernels = os.environ.get("DTF_PEER_KERNELS", "1") != "0"
@@ -120,6 +139,7 @@ class PeerRegion:
     def _init_cpu(self, cp, timeout_s):
         from multiprocessing import resource_tracker, shared_memory
         seg = "dtf_%s_%d" % (uuid.uuid4().hex[:12], self.rank)
+        _CREATED_HERE.add(seg)
         self._shm = shared_memory.SharedMemory(name=seg, create=True, size=max(self.nfloats * 4, 4))
         self.local = torch.frombuffer(self._shm.buf, dtype=torch.float32, count=self.nfloats)
         self.local.zero_()
@@ -130,10 +150,11 @@ class PeerRegion:
                 continue
             peer_name = cp.get("%s/handle/%d" % (self.name, r), timeout_s=timeout_s).decode()
             shm = shared_memory.SharedMemory(name=peer_name)
-            try:        # the attaching process must not unlink the creator's segment when it exits
-                resource_tracker.unregister(shm._name, "shared_memory")
-            except Exception:
-                pass
+            if shm._name.lstrip("/") not in _CREATED_HERE:
+                try:    # the attaching process must not unlink the creator's segment when it exits
+                    resource_tracker.unregister(shm._name, "shared_memory")
+                except Exception:
+                    pass
             self._peers_shm.append(shm)
             self._peer_views[r] = torch.frombuffer(shm.buf, dtype=torch.float32, count=self.sizes[r])
 
@@ -208,6 +229,42 @@ class PeerRegion:
         for j in range(self.world):
             self.put(j, dst_off, src[j * n:(j + 1) * n])
 
+    def make_ranges(self, ranges) -> RangeTable:
+        """Prepare ``ranges`` = ``[(peer, remote_off, local_off, n), ...]`` (floats) for ``move_ranges``."""
+        t = RangeTable(ranges)
+        for peer, roff, loff, n in t.ranges:
+            if not 0 <= peer < self.world or roff < 0 or loff < 0 or n < 0 or roff + n > self.sizes[peer]:
+                raise ValueError("range (%d, %d, %d, %d) outside rank %d's region" % (peer, roff, loff, n, peer))
+        vec = all(roff % 4 == 0 and loff % 4 == 0 and n % 4 == 0 for _, roff, loff, n in t.ranges)
+        if self._h is not None and self._kernels and vec and t.ranges:
+            arr = (_RangeDesc * len(t.ranges))()
+            for d, (peer, roff, loff, n) in zip(arr, t.ranges):
+                d.peer, d.remote_off, d.local_off, d.n16 = peer, roff * 4, loff * 4, n // 4
+            with torch.cuda.device(self.device):
+                t.handle = _k().dtf_mbox_ranges_create(self._h, arr, len(t.ranges))
+            if not t.handle:
+                raise RuntimeError("cannot build the range table")
+            self._tables.append(t)
+        return t
+
+    def move_ranges(self, table: RangeTable, gather: bool, remote_base: int, local: torch.Tensor):
+        """Every range of ``table`` at once: ``local[local_off:+n] = region[peer][remote_base + remote_off:+n]`` when
+        ``gather``, the other direction otherwise (GPU: one launch on the current stream, all peers in flight)."""
+        if local.dtype != torch.float32 or not local.is_contiguous():
+            raise ValueError("peer regions move contiguous float32 tensors")
+        if table.handle and remote_base % 4 == 0:
+            rc = _k().dtf_mbox_ranges_run(self._h, table.handle, 1 if gather else 0, int(remote_base) * 4, local.data_ptr(),
+                                          local.numel() * 4, torch.cuda.current_stream(self.device).cuda_stream)
+            if rc:
+                raise RuntimeError("peer range %s failed (%d)" % ("gather" if gather else "scatter", rc))
+            return
+        flat = local.reshape(-1)
+        for peer, roff, loff, n in table.ranges:
+            if gather:
+                self.get(peer, remote_base + roff, flat[loff:loff + n])
+            else:
+                self.put(peer, remote_base + roff, flat[loff:loff + n])
+
     def sync(self):
         """Wait until every put / get issued on the current stream has completed (and is visible to its target)."""
         if self._h is not None:
@@ -220,6 +277,11 @@ class PeerRegion:
         if h:
             self.local = None
             with torch.cuda.device(self.device):
+                for t in self._tables:
+                    if t.handle:
+                        _k().dtf_mbox_ranges_destroy(t.handle)
+                        t.handle = None
+                self._tables = []
                 _k().dtf_mbox_destroy(h)
         if self._shm is not None or self._peers_shm:
             # tensors made by frombuffer pin the mappings: drop them before closing
