@@ -68,6 +68,20 @@ def test_dense_backward_dw(gpu_device, M, K, N):
     torch.testing.assert_close(db, dz.double().sum(0).float(), **tol)
 
 
+@pytest.mark.parametrize("M,K,N", [(65536, 784, 128), (32768, 800, 64), (40000, 1056, 256), (30000, 200, 128)])
+def test_dense_backward_dw_partly_filled_last_row_tile_and_dirty_workspace(gpu_device, M, K, N):
+    """Weight gradients whose last row tile is at most half full (784 = 12 x 64 + 16, 800 = 12 x 64 + 32, ...), computed
+    in a caller-provided workspace that holds NaN: every slab element the reducer reads was written by a block."""
+    x, dz = _rand(M, K, device=gpu_device, seed=17), _rand(M, N, device=gpu_device, seed=18)
+    dw = torch.full((K, N), float("nan"), device=gpu_device)
+    db = torch.full((N,), float("nan"), device=gpu_device)
+    ws = torch.full((max(F.dense_dw_workspace_floats(M, N, K), 1),), float("nan"), device=gpu_device)
+    F.dense_backward_dw(x, dz, dw, db, workspace=ws)
+    tol = dict(rtol=2e-4, atol=3e-5 * max(M, 16) ** 0.5)
+    torch.testing.assert_close(dw, (x.double().t() @ dz.double()).float(), **tol)
+    torch.testing.assert_close(db, dz.double().sum(0).float(), **tol)
+
+
 def test_fused_dropout_matches_cpu_mask(gpu_device):
     M, K, N = 300, 64, 128
     x, w, b = _rand(M, K, device=gpu_device, seed=1), _rand(K, N, device=gpu_device, seed=2), _rand(N, device=gpu_device, seed=3)
