@@ -32,10 +32,11 @@ m.compile(loss="mean_squared_error", optimizer="adam", metrics=["accuracy"], str
 g = torch.Generator().manual_seed(index)
 x = torch.randint(0, 2, (50 * 64, 64), generator=g).float().to(device)
 y = torch.cat([(x[:, :32] != x[:, 32:]).float()], 1).to(device)
+step = m.train_step_graphed if (device != "cpu" and os.environ.get("GRAPHED", "0") == "1") else m.train_step
 def run(n):
     for i in range(n):
         lo = (i %% 64) * 50
-        m.train_step(x[lo:lo + 50], y[lo:lo + 50])
+        step(x[lo:lo + 50], y[lo:lo + 50])
     if device != "cpu":
         torch.cuda.synchronize()
 run(100)
@@ -93,8 +94,10 @@ def main():
                 return 1
             rows += [json.loads(l[7:]) for l in out.splitlines() if l.startswith("RESULT ")]
         total = sum(r["steps_per_s"] for r in rows)
-        print("%d ps + %d workers on %s, batch 50, plane %-6s: %.0f steps/s in total (%.0f us per step per worker), "
-              "%.2f control-plane calls per step" % (n_ps, n_w, device, rows[0]["plane"], total,
+        print("%d ps + %d workers on %s, batch 50, %s, plane %-6s: %.0f steps/s in total (%.0f us per step per worker), "
+              "%.2f control-plane calls per step" % (n_ps, n_w, device,
+                                                     "graph replay" if os.environ.get("GRAPHED", "0") == "1" else "eager launches",
+                                                     rows[0]["plane"], total,
                                                      sum(r["us_per_step"] for r in rows) / len(rows),
                                                      sum(r["control_calls_per_step"] for r in rows) / len(rows)), flush=True)
     return 0

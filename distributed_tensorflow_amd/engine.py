@@ -14,6 +14,8 @@ symbolic nodes onto the same fetch names.
 """
 from __future__ import annotations
 
+import os
+
 import json
 import uuid
 from typing import Any, Dict, List, Optional
@@ -77,6 +79,11 @@ class FeedStager:
 
 
 class ModelEngine:
+    # DTF_GRAPH_SMALL_STEPS=1: batches of up to 1024 rows replay forward + loss + backward from a hipGraph.  Off by
+    # default: with several tasks time-sharing one GPU a graph launch costs more than the dozen kernel launches it
+    # replaces (profiles/r3_async_ps_task_planes_b50.txt); one process per GPU may gain from it.
+    _graph_small_steps = os.environ.get("DTF_GRAPH_SMALL_STEPS", "0") == "1"
+
     def __init__(self, model, x_key="x", y_key="y", training_key="training"):
         self.model = model
         self.x_key, self.y_key, self.training_key = x_key, y_key, training_key
@@ -260,6 +267,9 @@ class ModelEngine:
                     else None
                 if plan is not None:
                     m.train_steps_fused(xd, yd, int(xd.shape[0]), 1, plan)     # the whole step in one launch
+                elif self._graph_small_steps and not isinstance(xd, tuple) and xd.is_cuda and xd.shape[0] <= 1024 \
+                        and hasattr(m, "train_step_graphed"):
+                    m.train_step_graphed(xd, yd)      # cluster strategies at launch-bound batch sizes
                 else:
                     m.train_step(xd, yd)
             else:

@@ -25,6 +25,8 @@ def _is_node(x) -> bool:
 
 
 class GraphModel(Sequential):
+    supports_gradient_graph = False      # the backward pass is PyTorch's autograd engine, not a fixed launch list
+
     def __init__(self, loss_node, inputs: Sequence[Any], labels: Sequence[Any], accuracy_node=None, output_node=None,
                  name: str = "graph_model"):
         super().__init__(name=name)

@@ -313,6 +313,27 @@ class Sequential:
         self.strategy.apply_gradients(self)
         self._host_step += 1
 
+    #: forward + loss + backward of this model can be captured in a hipGraph (static launch sequence)
+    supports_gradient_graph = True
+
+    def train_step_graphed(self, x: torch.Tensor, y: torch.Tensor):
+        """``train_step`` for launch-bound batches under a strategy that exchanges gradients after the backward pass
+        (asynchronous workers, un-overlapped synchronous replicas): the batch is copied into persistent buffers of its
+        shape and forward + loss + backward are replayed from one hipGraph - three host calls instead of one launch per
+        kernel; the strategy's exchange follows as usual.  Falls back to ``train_step`` where a graph cannot be used."""
+        if not (self.supports_gradient_graph and x.is_cuda and self._after_layer_backward is None):
+            return self.train_step(x, y)
+        key = ("stage", tuple(x.shape), tuple(y.shape), y.dtype)
+        bufs = self._graphs.get(key)
+        if bufs is None:
+            bufs = self._graphs[key] = (torch.empty_like(x, memory_format=torch.contiguous_format),
+                                        torch.empty_like(y, memory_format=torch.contiguous_format))
+        bufs[0].copy_(x)
+        bufs[1].copy_(y)
+        self.graphed_gradients(bufs[0], bufs[1]).replay()
+        self.strategy.apply_gradients(self)
+        self._host_step += 1
+
     # ------------------------------------------------------------------ statistics
     def read_stats(self, reset: bool = True, stats: Optional[torch.Tensor] = None) -> Dict[str, float]:
         """Mean loss / accuracy since the last reset (ONE device->host read)."""

@@ -107,6 +107,29 @@ def test_graph_replay_equals_eager(gpu_device):
     assert abs(ha.history["loss"][-1] - hb.history["loss"][-1]) < 1e-6
 
 
+def test_graphed_train_step_equals_eager(gpu_device):
+    """``train_step_graphed`` (persistent batch buffers + one hipGraph of forward, loss and backward, then the
+    strategy's apply) against ``train_step``: the same variables after 40 steps on varying batches, two batch shapes."""
+    xt, yt = get_data(2000, val_set_size=0, seed=4, device=gpu_device)[:2]
+    models = []
+    for _ in range(2):
+        m = xor_mlp()
+        m.compile(loss="mean_squared_error", optimizer="adam", metrics=["binary_rounded_accuracy"], device=gpu_device, seed=9)
+        models.append(m)
+    a, b = models
+    for la, lb in zip(a.layers, b.layers):
+        if hasattr(la, "seed"):
+            lb.seed = la.seed
+    for i in range(40):
+        n = 50 if i % 4 else 32                       # a second shape: its own buffers and graph
+        lo = (i * 50) % 1900
+        a.train_step(xt[lo:lo + n], yt[lo:lo + n])
+        b.train_step_graphed(xt[lo:lo + n], yt[lo:lo + n])
+    assert a.global_step == b.global_step == 40
+    torch.testing.assert_close(a.store.flat, b.store.flat, rtol=1e-5, atol=1e-7)
+    assert a.read_stats()["loss"] == pytest.approx(b.read_stats()["loss"], rel=1e-5)
+
+
 def test_mnist_mlp_learns_and_checkpoints(gpu_device, tmp_path):
     from distributed_tensorflow_amd.saver import Saver, list_variables
     x, y = mnist_like(16384, seed=0, device=gpu_device)
