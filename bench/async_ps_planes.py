@@ -42,7 +42,17 @@ def run(n):
 run(100)
 strat.cp0.barrier("warm", len(w_hosts), timeout_s=120)
 c0, t0 = strat.control_calls(), time.perf_counter()
-run(steps)
+if os.environ.get("PROFILE") == "1" and index == 0:
+    import cProfile, pstats, io
+    pr = cProfile.Profile()
+    pr.enable()
+    run(steps)
+    pr.disable()
+    out = io.StringIO()
+    pstats.Stats(pr, stream=out).sort_stats("tottime").print_stats(22)
+    sys.stderr.write(out.getvalue())
+else:
+    run(steps)
 dt = time.perf_counter() - t0
 calls = (strat.control_calls() - c0) / steps
 strat.worker_done()
@@ -88,6 +98,8 @@ def main():
                 if p.poll() is None:
                     p.kill()
         rows = []
+        if os.environ.get("PROFILE") == "1":
+            print(outs[n_ps][-6000:])
         for (job, i), p, out in zip(tasks, procs, outs):
             if p.returncode != 0:
                 print("== %s %d rc=%s\n%s" % (job, i, p.returncode, out[-2000:]))

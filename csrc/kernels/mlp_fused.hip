@@ -187,6 +187,7 @@ struct TileState {
     __device__ __forceinline__ void issue(const VarBufs& vb, long long off, int N, int i0, int n0, int lane) {
         const int li = lane & 31, h = lane >> 5;
         const int base = ((int)off + (i0 + 4 * h) * N + n0 + li) * 4;
+        if (OPT == 2) return;       // gradients only: no old values needed
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int bo = base + ((r & 3) + 8 * (r >> 2)) * N * 4;
@@ -207,6 +208,10 @@ struct TileState {
         for (int r = 0; r < 16; ++r) {
             const int rr = (r & 3) + 8 * (r >> 2);
             const int bo = base + rr * N * 4;
+            if (OPT == 2) {             // gradients only: vb.m is the gradient buffer, the variables stay as they are
+                vb_store(vb.m, bo, g[r]);
+                continue;
+            }
             if (SHARED) {
                 opt_update_shared<OPT>(o, vb.wptr, bo, m[r], v[r], g[r]);
                 if (OPT == 0) {
@@ -232,7 +237,7 @@ struct BiasState {
     float w, m, v;
     __device__ __forceinline__ void issue(const VarBufs& vb, long long off, int N, int tid) {
         w = m = v = 0.f;
-        if (tid < N) {
+        if (tid < N && OPT != 2) {
             const int bo = ((int)off + tid) * 4;
             w = vb_load(vb.w, bo);
             if (OPT == 0) {
@@ -255,6 +260,10 @@ struct BiasState {
                 s3 += dz[(r + 3) * ld + tid];
             }
             const int bo = ((int)off + tid) * 4;
+            if (OPT == 2) {
+                vb_store(vb.m, bo, (s0 + s1) + (s2 + s3));
+                return;
+            }
             if (SHARED) {
                 opt_update_shared<OPT>(o, vb.wptr, bo, m, v, (s0 + s1) + (s2 + s3));
                 if (OPT == 0) {
@@ -326,7 +335,7 @@ __global__ __launch_bounds__(NT, 1) void mlp3_fused_kernel(const FusedArgs p) {
     const unsigned W_BYTES = 0x7FFFFFF0u;
     VarBufs vb;
     vb.w = __builtin_amdgcn_make_buffer_rsrc(p.params, 0, (int)W_BYTES, 0x00020000);
-    vb.m = __builtin_amdgcn_make_buffer_rsrc(OPT == 0 ? p.slot_m : p.params, 0, (int)W_BYTES, 0x00020000);
+    vb.m = __builtin_amdgcn_make_buffer_rsrc(OPT != 1 ? p.slot_m : p.params, 0, (int)W_BYTES, 0x00020000);   // OPT 2: gradients
     vb.v = __builtin_amdgcn_make_buffer_rsrc(OPT == 0 ? p.slot_v : p.params, 0, (int)W_BYTES, 0x00020000);
     vb.wptr = p.params;
 
@@ -611,7 +620,7 @@ __global__ __launch_bounds__(NT, 1) void mlp3_fused_kernel(const FusedArgs p) {
             }
         }
     }
-    if (tid0 == 0 && last) {
+    if (tid0 == 0 && last && OPT != 2) {
         *p.step_ptr = step0 + p.nsteps;
         if (p.beta_powers && OPT == 0) {
             p.beta_powers[0] *= powf(p.beta1, (float)p.nsteps);
@@ -643,10 +652,11 @@ int launch_fused(FusedArgs a, int opt, hipStream_t stream) {
     constexpr size_t lds = sizeof(float) * LDS_FLOATS;
     static bool once = false;
     if (!once) {
-        const void* fns[4] = {reinterpret_cast<const void*>(mlp3_fused_kernel<0, false>),
+        const void* fns[5] = {reinterpret_cast<const void*>(mlp3_fused_kernel<0, false>),
                               reinterpret_cast<const void*>(mlp3_fused_kernel<1, false>),
                               reinterpret_cast<const void*>(mlp3_fused_kernel<0, true>),
-                              reinterpret_cast<const void*>(mlp3_fused_kernel<1, true>)};
+                              reinterpret_cast<const void*>(mlp3_fused_kernel<1, true>),
+                              reinterpret_cast<const void*>(mlp3_fused_kernel<2, false>)};
         for (const void* f : fns) {
             const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return (int)e;
@@ -661,6 +671,7 @@ int launch_fused(FusedArgs a, int opt, hipStream_t stream) {
         else hipLaunchKernelGGL((mlp3_fused_kernel<1, true>), grid, dim3(NT), lds, stream, a);
     } else {
         if (opt == 0) hipLaunchKernelGGL((mlp3_fused_kernel<0, false>), dim3(1), dim3(NT), lds, stream, a);
+        else if (opt == 2) hipLaunchKernelGGL((mlp3_fused_kernel<2, false>), dim3(1), dim3(NT), lds, stream, a);
         else hipLaunchKernelGGL((mlp3_fused_kernel<1, false>), dim3(1), dim3(NT), lds, stream, a);
     }
     DTF_CHECK_LAUNCH();
@@ -711,4 +722,24 @@ DTF_API int dtf_mlp3_fused_train(const float* X, const float* Y, float* params, 
     a.step_ptr = step_ptr; a.beta_powers = beta_powers; a.stats = stats; a.prof = g_prof_buffer;
     a.ctl = nullptr; a.workers = 1;
     return launch_fused(a, opt, stream);
+}
+
+// Forward, loss and backward of ONE mini-batch in one launch: the gradients of W1, b1, W2, b2, W3, b3 land in `grads`
+// at the variables' offsets, nothing else changes (no update, no step increment; the dropout masks are those of the
+// step `*step_ptr`).  What a replica of a cluster runs before it hands its gradients to the strategy - an asynchronous
+// worker's push to the parameter servers (/root/reference/example.py:168-170), a synchronous replica's all-reduce.
+DTF_API int dtf_mlp3_fused_grad(const float* X, const float* Y, const float* params, float* grads, const long long* offsets6,
+                                int d0, int d1, int d2, int d3, int B, int training, int want_cat, float keep1, float keep2,
+                                uint32_t seed1, uint32_t seed2, const long long* step_ptr, float* stats, hipStream_t stream) {
+    if (!dtf_mlp3_fused_supported(d0, d1, d2, d3, B)) return -4;
+    if (!grads || !params || !step_ptr) return -5;
+    FusedArgs a = {};
+    a.X = X; a.Y = Y; a.params = const_cast<float*>(params); a.slot_m = grads; a.slot_v = nullptr;
+    for (int i = 0; i < 6; ++i) a.off[i] = offsets6[i];
+    a.B = B; a.nsteps = 1; a.training = training; a.want_cat = want_cat;
+    a.keep1 = keep1; a.keep2 = keep2; a.seed1 = seed1; a.seed2 = seed2;
+    a.lr = 0.f; a.beta1 = 0.9f; a.beta2 = 0.999f; a.eps = 1e-8f;
+    a.step_ptr = const_cast<long long*>(step_ptr); a.beta_powers = nullptr; a.stats = stats; a.prof = nullptr;
+    a.ctl = nullptr; a.workers = 1;
+    return launch_fused(a, 2, stream);
 }

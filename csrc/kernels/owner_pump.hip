@@ -16,10 +16,13 @@
 //   (before reusing inbox[w][(t+D) % D]:                        ctl.version, ctl.global_step, lane[w].ack = t + 1
 //    wait until lane[w].ack > t)
 //
-// The words live in host memory shared by all processes of the node (one control block per owner); they are only
-// ever written by host code - a stream's host function runs after everything queued before it has completed, which
-// is the ordering and visibility the HIP runtime guarantees for copies and kernels.  The gradient and parameter data
-// itself stays in device memory (peer-mapped regions, see peer_mailbox.hip).
+// The words live in host memory shared by all processes of the node (one control block per owner).  On GPUs every
+// process registers the blocks with the HIP runtime, and the words are written by one-workgroup kernels queued right
+// behind the copies / the apply kernel on the same stream (stream order: the data is complete when the word changes;
+// the stores are system-scope releases into coherent host memory) - no host callback sits between a gradient's
+// arrival and its apply, or between the apply and its acknowledgement.  Without registered blocks
+// (DTF_DOORBELL_KERNELS=0) the same words are written by stream host functions instead.  The gradient and parameter
+// data itself stays in device memory (peer-mapped regions, see peer_mailbox.hip).
 //
 // On a CPU (the plumbing configuration and the tests) the same thread applies the update itself and the doorbell is
 // a plain store.
@@ -77,6 +80,7 @@ struct Config {
     float lr, b1, b2, eps, momentum;
     int pad2;
     void* ctl;
+    void* ctl_dev;                              // the control block as the GPU addresses it (registered host memory), or null
 };
 
 struct Pump;
@@ -99,6 +103,51 @@ struct Pump {
     std::vector<AckRecord> ring;                // records of acknowledgements in flight
     size_t ring_pos = 0;
 };
+
+// Word indices inside a lane / the header, in 64-bit units (the layout of Lane / Ctl above).
+constexpr int W_DOOR = 0, W_CLOCK = 1, W_PULLV = 2, W_ACK = 8, W_ACKV = 9;
+constexpr int W_VERSION = 0, W_GSTEP = 1;
+
+__device__ __forceinline__ void word_store(unsigned long long* p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void word_release(unsigned long long* p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Owner: the apply queued before this launch on the same stream is complete.  One thread per word (addresses come
+// from the thread index: vector stores), the acknowledgement itself last.
+__global__ __launch_bounds__(64) void ack_kernel(unsigned long long* ctl, int worker, int slot, unsigned long long seq,
+                                                 unsigned long long version, unsigned long long gstep, int owner0) {
+    unsigned long long* lane = ctl + 16 + 16 * worker;
+    const int t = threadIdx.x;
+    if (t == 0) word_store(lane + W_ACKV + slot, version);
+    if (t == 1) word_store(ctl + W_VERSION, version);
+    if (t == 2 && owner0) word_store(ctl + W_GSTEP, gstep);
+    __threadfence_system();
+    __syncthreads();
+    if (t == 0) word_release(lane + W_ACK, seq);
+}
+
+struct RingArgs {
+    unsigned long long* lane[64];
+    unsigned long long pulled[64];
+    int count, slot;
+    unsigned long long seq, clock;
+};
+
+// Worker: everything queued before this launch on the same stream (the gradient shards in the owners' inboxes) is
+// complete.  Thread i rings owner i.
+__global__ __launch_bounds__(64) void ring_kernel(RingArgs a) {
+    const int i = threadIdx.x;
+    if (i < a.count) {
+        unsigned long long* lane = a.lane[i];
+        word_store(lane + W_PULLV + a.slot, a.pulled[i]);
+        if (i == 0) word_store(lane + W_CLOCK, a.clock);      // lane[0] belongs to owner 0's block
+        __threadfence_system();
+        word_release(lane + W_DOOR, a.seq);
+    }
+}
 
 void acknowledge(const AckRecord& r) {
     Pump* p = r.pump;
@@ -184,7 +233,26 @@ void pump_loop(Pump* p, int device) {
             const int slot = (int)(seq % (uint64_t)c.depth);
             const float* g = c.inbox + ((long long)w * c.depth + slot) * c.slot_stride;
             AckRecord rec{p, w, slot, seq + 1, ++p->enqueued_version, lane.pull_version[slot]};
-            if (c.on_gpu) {
+            if (c.on_gpu && c.ctl_dev) {
+                // acknowledged by a kernel behind the apply; the applies of this owner are serial, so the version this
+                // one will leave behind - and with it the staleness of the gradient - is known now
+                int rc = gpu_apply(p, g);
+                if (rc == 0) {
+                    const uint64_t before = rec.version - 1;
+                    uint64_t st = before > rec.pulled ? before - rec.pulled : 0;
+                    if (st >= (uint64_t)PUMP_HIST) st = PUMP_HIST - 1;
+                    p->hist[st].fetch_add(1, std::memory_order_relaxed);
+                    hipLaunchKernelGGL(ack_kernel, dim3(1), dim3(64), 0, p->stream, static_cast<unsigned long long*>(c.ctl_dev), w,
+                                       slot, (unsigned long long)rec.seq, (unsigned long long)rec.version,
+                                       (unsigned long long)(p->ctl->gs_base.load(std::memory_order_relaxed) + rec.version),
+                                       c.owner == 0 ? 1 : 0);
+                    rc = (int)hipGetLastError();
+                }
+                if (rc != 0) {
+                    p->error.store(rc);
+                    return;
+                }
+            } else if (c.on_gpu) {
                 int rc = gpu_apply(p, g);
                 AckRecord* slot_rec = &p->ring[p->ring_pos];
                 p->ring_pos = (p->ring_pos + 1) % p->ring.size();
@@ -319,11 +387,24 @@ DTF_API int dtf_pump_stop(void* h) {
 // Worker side: after everything queued on `stream` so far (the puts of this step's gradient shards), tell `count`
 // owners that gradient number `seq` (1-based) of this worker is complete in slot `slot` of their inboxes.
 // `lanes[i]` is this worker's lane in owner i's control block, `pulled[i]` the owner version the gradient was
-// computed from.  `clock` is published in lanes[0] (owner 0's block) for the staleness bound.  stream == null on a
-// CPU: the stores happen now.
-DTF_API int dtf_doorbell_ring(hipStream_t stream, int on_gpu, void* const* lanes, const unsigned long long* pulled, int count,
-                              int slot, unsigned long long seq, unsigned long long clock) {
+// computed from.  `clock` is published in lanes[0] (owner 0's block) for the staleness bound.  `lanes_dev` (GPU
+// only, may be null): the same lanes as the GPU addresses them - the words are then written by a kernel on `stream`;
+// otherwise by a host function on it.  stream == null on a CPU: the stores happen now.
+DTF_API int dtf_doorbell_ring(hipStream_t stream, int on_gpu, void* const* lanes, void* const* lanes_dev,
+                              const unsigned long long* pulled, int count, int slot, unsigned long long seq,
+                              unsigned long long clock) {
     if (count < 1 || count > 64 || slot < 0 || slot >= PUMP_MAX_DEPTH) return -2;
+    if (on_gpu && lanes_dev) {
+        RingArgs a;
+        a.count = count; a.slot = slot; a.seq = seq; a.clock = clock;
+        for (int i = 0; i < count; ++i) {
+            if (!lanes_dev[i]) return -2;
+            a.lane[i] = static_cast<unsigned long long*>(lanes_dev[i]);
+            a.pulled[i] = pulled[i];
+        }
+        hipLaunchKernelGGL(ring_kernel, dim3(1), dim3(64), 0, stream, a);
+        return (int)hipGetLastError();
+    }
     auto* r = new RingRecord();
     r->count = count;
     r->slot = slot;
@@ -344,4 +425,80 @@ DTF_API int dtf_doorbell_ring(hipStream_t stream, int on_gpu, void* const* lanes
         return (int)e;
     }
     return 0;
+}
+
+// Host memory shared between processes (the control blocks) made addressable by this process's GPU: returns the device
+// alias through `dev_out`.  The mapping is coherent: a GPU store is seen by a polling CPU thread of any process.
+DTF_API int dtf_host_register(void* host, long long bytes, void** dev_out) {
+    if (!host || bytes <= 0 || !dev_out) return -2;
+    hipError_t e = hipHostRegister(host, (size_t)bytes, hipHostRegisterMapped | hipHostRegisterPortable);
+    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
+    e = hipHostGetDevicePointer(dev_out, host, 0);
+    if (e != hipSuccess) { (void)hipGetLastError(); (void)hipHostUnregister(host); return (int)e; }
+    return 0;
+}
+
+DTF_API int dtf_host_unregister(void* host) { return host ? (int)hipHostUnregister(host) : 0; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// A worker's link to its owners: the communication stream and the two events of the push choreography, so that one
+// native call does what the step needs - order the copies behind the backward pass, move the gradient into the
+// owners' inboxes, ring the doorbells, and let the compute stream reuse the gradient buffer once it has been read.
+extern "C" int dtf_mbox_ranges_run(void* h, void* table, int gather, long long remote_base, void* local, long long local_bytes,
+                                   hipStream_t stream);
+extern "C" int dtf_mbox_scatter(void* h, long long dst_off, const void* src, long long shard_bytes, hipStream_t stream);
+
+namespace {
+struct Link {
+    hipStream_t comm = nullptr;
+    hipEvent_t ev_grad = nullptr, ev_copied = nullptr;
+};
+}  // namespace
+
+DTF_API void* dtf_link_create() {
+    auto* l = new Link();
+    if (hipStreamCreateWithFlags(&l->comm, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&l->ev_grad, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&l->ev_copied, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        if (l->ev_grad) (void)hipEventDestroy(l->ev_grad);
+        if (l->comm) (void)hipStreamDestroy(l->comm);
+        delete l;
+        return nullptr;
+    }
+    return l;
+}
+
+DTF_API void dtf_link_destroy(void* h) {
+    auto* l = static_cast<Link*>(h);
+    if (!l) return;
+    (void)hipStreamSynchronize(l->comm);
+    (void)hipEventDestroy(l->ev_grad);
+    (void)hipEventDestroy(l->ev_copied);
+    (void)hipStreamDestroy(l->comm);
+    delete l;
+}
+
+DTF_API void* dtf_link_stream(void* h) { return static_cast<Link*>(h)->comm; }
+
+// One training step's push.  `table` != null: the gradient's flat ranges go to `remote_base` of the owners' regions
+// (ps tasks as owners); else shard j of `grad` (shard_bytes each) goes to offset `remote_base` of rank j's region
+// (owners colocated with the workers).  Offsets in bytes.  Everything is queued; nothing waits on the host.
+DTF_API int dtf_link_push(void* link, void* mbox, void* table, hipStream_t cur, const void* grad, long long grad_bytes,
+                          long long remote_base, long long shard_bytes, void* const* lanes, void* const* lanes_dev,
+                          const unsigned long long* pulled, int count, int slot, unsigned long long seq,
+                          unsigned long long clock) {
+    auto* l = static_cast<Link*>(link);
+    if (!l || !mbox || !grad) return -2;
+    hipError_t e = hipEventRecord(l->ev_grad, cur);
+    if (e == hipSuccess) e = hipStreamWaitEvent(l->comm, l->ev_grad, 0);
+    if (e != hipSuccess) return (int)e;
+    int rc = table ? dtf_mbox_ranges_run(mbox, table, 0, remote_base, const_cast<void*>(grad), grad_bytes, l->comm)
+                   : dtf_mbox_scatter(mbox, remote_base, grad, shard_bytes, l->comm);
+    if (rc) return rc;
+    e = hipEventRecord(l->ev_copied, l->comm);
+    if (e != hipSuccess) return (int)e;
+    rc = dtf_doorbell_ring(l->comm, 1, lanes, lanes_dev, pulled, count, slot, seq, clock);
+    if (rc) return rc;
+    return (int)hipStreamWaitEvent(cur, l->ev_copied, 0);     // the next backward pass may overwrite the gradient buffer
 }

@@ -13,6 +13,7 @@ replay many steps from one captured hipGraph when batches are launch-bound.
 from __future__ import annotations
 
 import math
+import os
 import time
 from typing import Dict, List, Optional, Sequence
 
@@ -25,6 +26,13 @@ from ..layers import Conv2D, Dense, Dropout, Layer, MaxPooling2D
 from ..ops import functional as F
 from ..ops._native import ACT_NONE, ACT_RELU, ACT_SIGMOID
 from ..variables import VariableStore
+
+_FUSED_GRAD = os.environ.get("DTF_FUSED_GRAD", "1") != "0"
+
+
+def nv_kernels():
+    from ..ops import _native as nv
+    return nv.kernels()
 
 
 def default_device() -> torch.device:
@@ -298,8 +306,39 @@ class Sequential:
             if g is None:
                 break
 
+    def fused_grad_plan(self, batch_size: int):
+        """Arguments for the one-launch gradient kernel (``dtf_mlp3_fused_grad``) when this model is the reference
+        network shape at a batch of at most 64 on the GPU and trains under a cluster strategy that takes the gradients
+        after the backward pass (asynchronous workers, un-overlapped synchronous replicas); ``None`` otherwise.
+        ``DTF_FUSED_GRAD=0`` keeps the layer-by-layer kernels."""
+        if not self.compiled or self.device is None or self.device.type != "cuda" or not _FUSED_GRAD:
+            return None
+        if type(self.strategy) is LocalStrategy or self._after_layer_backward is not None:
+            return None         # a single replica has the whole-step kernel (fused_step_plan)
+        key = ("grad", int(batch_size))
+        if key not in self._fused_plans:
+            plan = None
+            eff = self._effective
+            if len(eff) == 3 and all(isinstance(l, Dense) and l.bias is not None and not l.softmax for l in eff) \
+                    and [l.act for l in eff] == [ACT_RELU, ACT_RELU, ACT_SIGMOID] and eff[2].fused_keep >= 1.0 \
+                    and not any(isinstance(l, Dropout) and not l.fused_into_previous and l.rate > 0.0 for l in self.layers) \
+                    and isinstance(self.loss, losses_mod.MeanSquaredError):
+                dims = (eff[0].kernel.shape[0], eff[0].units, eff[1].units, eff[2].units)
+                if F.mlp3_fused_supported(dims, batch_size) and hasattr(nv_kernels(), "dtf_mlp3_fused_grad"):
+                    plan = dict(dims=dims, offsets=[v.offset for l in eff for v in (l.kernel, l.bias)], l1=eff[0], l2=eff[1])
+            self._fused_plans[key] = plan
+        return self._fused_plans[key]
+
     def compute_gradients(self, x, y, stats: Optional[torch.Tensor] = None):
         """Forward + loss + backward: leaves dL/dvar in ``store.flat_grad`` (no variable update)."""
+        if x.is_cuda and x.dim() == 2 and y.dim() == 2 and y.dtype == torch.float32 and x.shape[0] <= 64:
+            gp = self.fused_grad_plan(int(x.shape[0]))
+            if gp is not None:
+                st = self.store
+                F.mlp3_fused_grad(x.contiguous(), y.contiguous(), st.flat, st.flat_grad, gp["offsets"], gp["dims"], True,
+                                  self._extra_categorical, gp["l1"].fused_keep, gp["l2"].fused_keep, gp["l1"].seed,
+                                  gp["l2"].seed, st.global_step, self.stats if stats is None else stats)
+                return
         plan = self.tail_plan() if (x.is_cuda and y.dtype == torch.int64 and y.dim() == 1) else None
         if plan is not None:
             return self._compute_gradients_tail(x, y.contiguous(), self.stats if stats is None else stats, plan)

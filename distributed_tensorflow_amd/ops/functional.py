@@ -530,6 +530,32 @@ def mlp3_fused_train(x, y, params, slot_m, slot_v, offsets, dims, batch, nsteps,
     nv.check(rc, "dtf_mlp3_fused_train")
 
 
+def mlp3_fused_grad(x, y, params, grads, offsets, dims, training, want_cat, keep1, keep2, seed1, seed2, step, stats):
+    """Forward, MSE loss (+ metrics into ``stats``) and backward of the reference MLP on ONE mini-batch in one launch:
+    the gradients land in ``grads`` at the variables' ``offsets``; variables, step counter and optimizer state are not
+    touched.  GPU only; batch <= 64."""
+    import ctypes as C
+    nv.require_f32_contig(x, y, params, grads)
+    if not x.is_cuda:
+        raise ValueError("the fused gradient kernel runs on the GPU only")
+    batch = int(x.shape[0])
+    if y.shape[0] != batch or x.shape[1] != dims[0] or y.shape[1] != dims[3]:
+        raise ValueError("fused gradients: batch %s/%s does not match %s" % (tuple(x.shape), tuple(y.shape), (dims[0], dims[3])))
+    need = max(offsets[0] + dims[0] * dims[1], offsets[2] + dims[1] * dims[2], offsets[4] + dims[2] * dims[3],
+               offsets[1] + dims[1], offsets[3] + dims[2], offsets[5] + dims[3])
+    if params.numel() < need or grads.numel() < need:
+        raise ValueError("fused gradients: flat buffers are shorter than the layout (%d)" % need)
+    if any(o % 4 for o in offsets):
+        raise ValueError("fused gradients: variable offsets must be multiples of 4 elements")
+    offs = (C.c_longlong * 6)(*[int(o) for o in offsets])
+    fn = nv.declare(nv.kernels(), "dtf_mlp3_fused_grad",
+                    [nv.c_p] * 5 + [nv.c_i] * 7 + [nv.c_f, nv.c_f, nv.c_u32, nv.c_u32] + [nv.c_p] * 3)
+    rc = fn(nv.ptr(x), nv.ptr(y), nv.ptr(params), nv.ptr(grads), C.cast(offs, C.c_void_p), int(dims[0]), int(dims[1]),
+            int(dims[2]), int(dims[3]), batch, int(bool(training)), int(bool(want_cat)), float(keep1), float(keep2),
+            int(seed1) & _M32, int(seed2) & _M32, nv.ptr(step), nv.ptr(stats), nv.stream_ptr())
+    nv.check(rc, "dtf_mlp3_fused_grad")
+
+
 # ----------------------------------------------------------------------------- convolution support (NHWC)
 def conv_geometry(H, W, KH, KW, strides=(1, 1), padding="valid"):
     """Output size and top/left zero padding, TensorFlow rules ('same': out = ceil(in / stride), extra padding goes

@@ -342,6 +342,7 @@ class ParameterServerService:
                                  sizes=sizes)
         self.blocks = ControlBlocks(self.rank, world, self.cp0, name=self.ns + "/ctl", lanes=self.num_workers,
                                     owner_rank=srv.ps_rank)
+        self.blocks.register_device(self.device, ranks=[self.rank])     # acknowledgements from a kernel behind the apply
         self._owns_region = True
 
     def _configure(self, layout: dict):
@@ -376,7 +377,8 @@ class ParameterServerService:
                               n=self.n, slot_stride=S, var=self.var, m=self.slots.get("m", self.slots.get("momentum")),
                               v=self.slots.get("v"), inbox=self.region.local[3 * S:], step=self.step_t,
                               beta_powers=self.beta_powers, optimizer=self.opt,
-                              ctl_address=self.blocks.block_address(self.owner_index))
+                              ctl_address=self.blocks.block_address(self.owner_index),
+                              ctl_dev_address=self.blocks.block_dev_address(self.owner_index))
 
     def _quiesce(self):
         """Stop applying (what is launched completes): the shard is stable until ``_release``."""
@@ -687,6 +689,8 @@ class AsyncPSStrategy:
         self.elastic = False          # DTF_ELASTIC_WORKERS=1: workers may die and be re-admitted (ps tasks own all state)
         self._rejoined = False        # this process replaced a worker that died
         self._range_table = None      # peer_region.RangeTable of the owners' flat ranges (ps tasks on the region plane)
+        self._link = None             # doorbell.PushLink: the native push of a GPU worker (stream, events, doorbells)
+        self._lanes_dev = None        # without a link: this worker's lanes as the GPU addresses them
         self.blocks = None            # doorbell.ControlBlocks: the owners' words (region plane)
         self.depth = 1                # inbox slots per (owner, worker): gradients a worker may have outstanding
         self._pulled: List[int] = []  # owner versions seen at the last pull
@@ -880,8 +884,23 @@ class AsyncPSStrategy:
             self._sent_pulled = [[0] * self.num_owners for _ in range(self.depth)]
             self._acked = [0] * self.num_owners
             if dev.type == "cuda":
-                self._comm_stream = torch.cuda.Stream(device=dev)
-                self._ev_grad, self._ev_copied = torch.cuda.Event(), torch.cuda.Event()
+                # the owners' words as this GPU addresses them (colocated: this rank's own block too, for its pump)
+                self.blocks.register_device(dev)
+                w = self.worker_index
+                lanes_dev = [self.blocks.lane_dev_address(j, w) for j in range(self.num_owners)]
+                S = self.slot_len
+                if self.region._kernels and (not self.colocated or (S % 4 == 0 and store.flat_len == S * self.num_owners)):
+                    from .doorbell import PushLink
+                    self._link = PushLink(dev, self.region, None if self.colocated else self._owner_ranges_table(),
+                                          [self.blocks.lane_address(j, w) for j in range(self.num_owners)],
+                                          lanes_dev if all(lanes_dev) else None)
+                    if not self.colocated and not self._range_table.handle:
+                        self._link.close()
+                        self._link = None
+                if self._link is None:
+                    self._lanes_dev = lanes_dev if all(lanes_dev) else None
+                    self._comm_stream = torch.cuda.Stream(device=dev)
+                    self._ev_grad, self._ev_copied = torch.cuda.Event(), torch.cuda.Event()
         if self._service_thread is not None:
             self._service_thread.start()
         if self.region is not None:
@@ -957,6 +976,9 @@ class AsyncPSStrategy:
                     pass
                 t.join(10.0)
         if self.region is not None and (t is None or not t.is_alive()):
+            if self._link is not None:
+                self._link.close()
+                self._link = None
             self.region.close()
             self.region = None
             if self.blocks is not None:
@@ -1058,15 +1080,16 @@ class AsyncPSStrategy:
             self._range_table = self.region.make_ranges(descs)
         return self._range_table
 
-    def _region_pull(self, store):
+    def _region_pull(self, store, stream_ptr: Optional[int] = None):
         """One-sided gets of every owner's variables straight into the flat buffer, on the current stream."""
         for j in range(self.num_owners):
             self._pulled[j] = self.blocks.version(j)
         if self.colocated:
-            self.region.gather(0, store.flat)            # owner j's shard is flat[j*S:(j+1)*S]: one launch, all links
+            # owner j's shard is flat[j*S:(j+1)*S]: one launch, all links
+            self.region.gather(0, store.flat, stream_ptr=stream_ptr)
         else:
             # ps tasks: the flat ranges of the variables each one owns, all owners in one launch
-            self.region.move_ranges(self._owner_ranges_table(), True, 0, store.flat)
+            self.region.move_ranges(self._owner_ranges_table(), True, 0, store.flat, stream_ptr=stream_ptr)
         self.versions = list(self._pulled)
         self.last_global_step = self.blocks.global_step()
 
@@ -1081,28 +1104,17 @@ class AsyncPSStrategy:
         if t >= D:
             self.wait_seconds += self._spin(lambda: self._min_ack() >= t + 1 - D, "a free inbox slot")
         self._account_acks()
-        if on_gpu:
-            cur = torch.cuda.current_stream(store.device)
-            self._ev_grad.record(cur)
-            self._comm_stream.wait_event(self._ev_grad)
-            ctx = torch.cuda.stream(self._comm_stream)
+        inbox = 3 * self.slot_len + (w * D + slot) * self.slot_len
+        self._sent_pulled[slot] = list(self._pulled)
+        cur_ptr = None
+        if self._link is not None:
+            # one native call queues the whole push: order behind the backward pass, gradient into the owners' inboxes
+            # (one launch), doorbells, release of the gradient buffer
+            cur_ptr = torch.cuda.current_stream(store.device).cuda_stream
+            self._link.push(cur_ptr, store.flat_grad, inbox, self.slot_len if self.colocated else 0, self._pulled, slot,
+                            t + 1, t + 1)
         else:
-            ctx = _NullContext()
-        with ctx:
-            inbox = 3 * self.slot_len + (w * D + slot) * self.slot_len
-            if self.colocated:
-                # shard j of the gradient into this worker's slot of owner j's inbox: one launch, all links at once
-                self.region.scatter(inbox, store.flat_grad)
-            else:
-                self.region.move_ranges(self._owner_ranges_table(), False, inbox, store.flat_grad)
-            if on_gpu:
-                self._ev_copied.record(self._comm_stream)
-            from .doorbell import ring
-            self._sent_pulled[slot] = list(self._pulled)
-            ring(self._comm_stream.cuda_stream if on_gpu else 0, on_gpu,
-                 [self.blocks.lane_address(j, w) for j in range(W)], self._pulled, slot, t + 1, t + 1)
-        if on_gpu:
-            cur.wait_event(self._ev_copied)              # the next backward pass may overwrite the gradient buffer
+            self._push_stepwise(store, on_gpu, inbox, slot, t + 1)
         self.clock = t + 1
         # how far this worker may run ahead of the owners: one gradient in flight per spare inbox slot
         lag = D - 1
@@ -1114,9 +1126,33 @@ class AsyncPSStrategy:
             if self.clock - self.min_clock() > s:
                 self.wait_seconds += self._spin(lambda: self.clock - self.min_clock() <= s,
                                                 "the slowest worker (staleness bound)")
-        self._region_pull(store)
+        self._region_pull(store, cur_ptr)
         if self.last_global_step:
             store.global_step.fill_(self.last_global_step)
+
+    def _push_stepwise(self, store, on_gpu: bool, inbox: int, slot: int, seq: int):
+        """The push without the native link (CPUs; GPUs with DTF_PEER_KERNELS=0): the same steps, one call each."""
+        from .doorbell import ring
+        W, w = self.num_owners, self.worker_index
+        if on_gpu:
+            cur = torch.cuda.current_stream(store.device)
+            self._ev_grad.record(cur)
+            self._comm_stream.wait_event(self._ev_grad)
+            ctx = torch.cuda.stream(self._comm_stream)
+        else:
+            ctx = _NullContext()
+        with ctx:
+            if self.colocated:
+                # shard j of the gradient into this worker's slot of owner j's inbox: one launch, all links at once
+                self.region.scatter(inbox, store.flat_grad)
+            else:
+                self.region.move_ranges(self._owner_ranges_table(), False, inbox, store.flat_grad)
+            if on_gpu:
+                self._ev_copied.record(self._comm_stream)
+            ring(self._comm_stream.cuda_stream if on_gpu else 0, on_gpu,
+                 [self.blocks.lane_address(j, w) for j in range(W)], self._pulled, slot, seq, seq, self._lanes_dev)
+        if on_gpu:
+            cur.wait_event(self._ev_copied)              # the next backward pass may overwrite the gradient buffer
 
     def min_clock(self) -> int:
         """The slowest worker's clock (pushes completed), as the staleness bound sees it."""

@@ -4,7 +4,10 @@ Every owner has one *control block* in host memory shared by all processes of th
 header (``version``, ``global_step``) and one 128-byte *lane* per worker with the worker's doorbell / clock and the
 owner's acknowledgement.  Workers and owners exchange gradients and parameters through peer-mapped device memory
 (:mod:`.peer_region`); these words are all that tells the other side that data is complete, so a training step makes
-no control-plane round trip and never synchronises a stream on the host.  The layout is the one of
+no control-plane round trip and never synchronises a stream on the host.  On GPUs every process registers the blocks
+with the HIP runtime (``ControlBlocks.register_device``) and the words are written by one-workgroup kernels queued
+behind the copies / the apply kernel (system-scope release stores into coherent host memory); a GPU worker's whole
+push is one native call (:class:`PushLink`).  The layout is the one of
 ``csrc/kernels/owner_pump.hip`` (``Ctl`` / ``Lane``), which also holds the owner's service thread.
 
 The reference's counterpart is TF's gRPC worker service inside ``server.join()``
@@ -49,7 +52,13 @@ def _k():
         nv.declare(lib, "dtf_pump_stream", [p], p)
         nv.declare(lib, "dtf_pump_histogram", [p, p], None)
         nv.declare(lib, "dtf_pump_stop", [p])
-        nv.declare(lib, "dtf_doorbell_ring", [p, C.c_int, p, p, C.c_int, C.c_int, ull, ull])
+        nv.declare(lib, "dtf_doorbell_ring", [p, C.c_int, p, p, p, C.c_int, C.c_int, ull, ull])
+        nv.declare(lib, "dtf_host_register", [p, ll, p])
+        nv.declare(lib, "dtf_host_unregister", [p])
+        nv.declare(lib, "dtf_link_create", [], p)
+        nv.declare(lib, "dtf_link_destroy", [p], None)
+        nv.declare(lib, "dtf_link_stream", [p], p)
+        nv.declare(lib, "dtf_link_push", [p, p, p, p, p, ll, ll, ll, p, p, p, C.c_int, C.c_int, ull, ull])
         assert lib.dtf_pump_lane_bytes() == _LANE_WORDS * 8
         _lib = lib
     return _lib
@@ -62,7 +71,7 @@ class _PumpConfig(C.Structure):
                 ("var", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("inbox", C.c_void_p),
                 ("step", C.c_void_p), ("beta_powers", C.c_void_p), ("ticket", C.c_void_p),
                 ("lr", C.c_float), ("b1", C.c_float), ("b2", C.c_float), ("eps", C.c_float), ("momentum", C.c_float),
-                ("pad2", C.c_int), ("ctl", C.c_void_p)]
+                ("pad2", C.c_int), ("ctl", C.c_void_p), ("ctl_dev", C.c_void_p)]
 
 
 class ControlBlocks:
@@ -99,8 +108,42 @@ class ControlBlocks:
             self._shms[r] = shm
         self.words = [np.frombuffer(s.buf, dtype=np.uint64, count=nbytes // 8) for s in self._shms]
         self._base = [C.addressof(C.c_char.from_buffer(s.buf)) for s in self._shms]
+        self._nbytes = nbytes
+        self._dev_base: List[Optional[int]] = [None] * self.world       # the blocks as this process's GPU addresses them
+        self._registered: List[int] = []
         if not rejoin:      # a restarted process maps the blocks of ranks that have been running for a while
             cp.barrier("%s/mapped" % name, self.world, timeout_s=timeout_s)
+
+    # ---- GPU access to the words
+    def register_device(self, device, ranks=None) -> bool:
+        """Make the blocks of ``ranks`` (default: all) addressable by this process's GPU, so that doorbells and
+        acknowledgements are written by kernels in stream order instead of host callbacks.  ``DTF_DOORBELL_KERNELS=0``
+        (or a runtime that refuses to register shared memory) keeps the host functions; returns whether kernels are on."""
+        import os
+        if torch.device(device).type != "cuda" or os.environ.get("DTF_DOORBELL_KERNELS", "1") == "0":
+            return False
+        lib = _k()
+        with torch.cuda.device(device):
+            for r in (range(self.world) if ranks is None else ranks):
+                if self._dev_base[r] is not None:
+                    continue
+                out = C.c_void_p()
+                if lib.dtf_host_register(C.c_void_p(self._base[r]), self._nbytes, C.byref(out)) or not out.value:
+                    for b in self._registered:
+                        lib.dtf_host_unregister(C.c_void_p(b))
+                    self._registered = []
+                    self._dev_base = [None] * self.world
+                    return False
+                self._registered.append(self._base[r])
+                self._dev_base[r] = out.value
+        return True
+
+    def block_dev_address(self, owner: int) -> Optional[int]:
+        return self._dev_base[self._blk(owner)]
+
+    def lane_dev_address(self, owner: int, worker: int) -> Optional[int]:
+        b = self._dev_base[self._blk(owner)]
+        return None if b is None else b + (_HDR_WORDS + _LANE_WORDS * worker) * 8
 
     # ---- addresses for the native side
     def block_address(self, owner: int) -> int:
@@ -159,6 +202,11 @@ class ControlBlocks:
         w[_GSTEP] = np.uint64(int(global_step))
 
     def close(self):
+        if self._registered:
+            lib = _k()
+            for b in self._registered:
+                lib.dtf_host_unregister(C.c_void_p(b))
+            self._registered = []
         self.words = []
         self._base = []
         for i, s in enumerate(self._shms):
@@ -175,22 +223,64 @@ class ControlBlocks:
         self._shms = []
 
 
-def ring(stream_ptr: int, on_gpu: bool, lanes: List[int], pulled: List[int], slot: int, seq: int, clock: int):
+def ring(stream_ptr: int, on_gpu: bool, lanes: List[int], pulled: List[int], slot: int, seq: int, clock: int,
+         lanes_dev: Optional[List[int]] = None):
     """After everything queued on the stream so far: publish gradient number ``seq`` of this worker (slot ``slot`` of
-    the inboxes) to the owners whose lanes are given; ``lanes[0]`` must be the lane in owner 0's block."""
+    the inboxes) to the owners whose lanes are given; ``lanes[0]`` must be the lane in owner 0's block.  ``lanes_dev``:
+    the lanes as the GPU addresses them (``ControlBlocks.register_device``): a kernel writes the words."""
     n = len(lanes)
     la = (C.c_void_p * n)(*lanes)
+    ld = (C.c_void_p * n)(*lanes_dev) if lanes_dev else None
     pv = (C.c_ulonglong * n)(*pulled)
-    rc = _k().dtf_doorbell_ring(C.c_void_p(stream_ptr or 0), 1 if on_gpu else 0, la, pv, n, int(slot), int(seq), int(clock))
+    rc = _k().dtf_doorbell_ring(C.c_void_p(stream_ptr or 0), 1 if on_gpu else 0, la, ld, pv, n, int(slot), int(seq), int(clock))
     if rc:
         raise RuntimeError("doorbell failed (%d)" % rc)
+
+
+class PushLink:
+    """A GPU worker's native link to its owners (``dtf_link_*`` in ``csrc/kernels/owner_pump.hip``): the communication
+    stream and events of the push, the lane addresses, and one call per step that queues everything - wait for the
+    backward pass, move the gradient into the owners' inboxes, ring the doorbells, release the gradient buffer."""
+
+    def __init__(self, device, region, table, lanes: List[int], lanes_dev: Optional[List[int]]):
+        self.device = torch.device(device)
+        lib = _k()
+        with torch.cuda.device(self.device):
+            self._h = lib.dtf_link_create()
+        if not self._h:
+            raise RuntimeError("cannot create the push link")
+        self._region, self._table = region, table
+        n = self.n = len(lanes)
+        self._lanes = (C.c_void_p * n)(*lanes)
+        self._lanes_dev = (C.c_void_p * n)(*lanes_dev) if lanes_dev else None
+        self._pulled = (C.c_ulonglong * n)()
+
+    def stream_ptr(self) -> int:
+        return _k().dtf_link_stream(self._h)
+
+    def push(self, cur_stream_ptr: int, grad: torch.Tensor, remote_base: int, shard_floats: int, pulled: List[int], slot: int,
+             seq: int, clock: int):
+        for i, v in enumerate(pulled):
+            self._pulled[i] = v
+        rc = _k().dtf_link_push(self._h, self._region._h, self._table.handle if self._table is not None else None,
+                                C.c_void_p(cur_stream_ptr or 0), grad.data_ptr(), grad.numel() * 4, int(remote_base) * 4,
+                                int(shard_floats) * 4, self._lanes, self._lanes_dev, self._pulled, self.n, int(slot), int(seq),
+                                int(clock))
+        if rc:
+            raise RuntimeError("push to the owners failed (%d)" % rc)
+
+    def close(self):
+        h, self._h = self._h, None
+        if h:
+            with torch.cuda.device(self.device):
+                _k().dtf_link_destroy(h)
 
 
 class OwnerPump:
     """The owner's native service thread: applies arriving gradient shards to ``var`` / slots on its own stream."""
 
     def __init__(self, *, device, owner: int, workers: int, depth: int, n: int, slot_stride: int, var, m, v, inbox,
-                 step, beta_powers, optimizer, ctl_address: int):
+                 step, beta_powers, optimizer, ctl_address: int, ctl_dev_address: Optional[int] = None):
         lib = _k()
         assert lib.dtf_pump_config_bytes() == C.sizeof(_PumpConfig), "owner_pump.hip and doorbell.py disagree"
         self.device = torch.device(device)
@@ -210,6 +300,7 @@ class OwnerPump:
         else:
             cfg.lr, cfg.b1, cfg.b2, cfg.eps, cfg.momentum = optimizer.lr, 0.0, 0.0, 0.0, optimizer.momentum
         cfg.ctl = ctl_address
+        cfg.ctl_dev = ctl_dev_address if on_gpu else None     # acknowledgements written by a kernel behind the apply
         if on_gpu:
             with torch.cuda.device(self.device):
                 self._h = lib.dtf_pump_start(C.byref(cfg))
@@ -250,8 +341,8 @@ def spin_until(pred, timeout_s: float, what: str, check=None):
     n = 0
     while not pred():
         n += 1
-        if n > 50:
-            time.sleep(0.00005 if n < 2000 else 0.0005)
+        if n > 150:         # ~0.2 ms of polling first: a sleep, however short it is asked to be, costs ~0.1 ms
+            time.sleep(0.00002 if n < 2000 else 0.0005)
         if n % 256 == 0:
             if check is not None:
                 check()

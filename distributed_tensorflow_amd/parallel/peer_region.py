@@ -192,7 +192,7 @@ class PeerRegion:
         else:
             dst.reshape(-1).copy_(self._peer_views[peer][src_off:src_off + dst.numel()])
 
-    def gather(self, src_off: int, dst: torch.Tensor):
+    def gather(self, src_off: int, dst: torch.Tensor, stream_ptr: Optional[int] = None):
         """``dst[j*n:(j+1)*n] = region[j][src_off : src_off + n]`` for every rank ``j`` (``n = dst.numel() / world``).
         On GPUs one kernel launch reads from all peers at once, so every xGMI link of this GPU carries its shard
         concurrently; a chain of per-peer copies on one stream would use the point-to-point links one at a time."""
@@ -204,7 +204,8 @@ class PeerRegion:
             return
         if self._h is not None and n % 4 == 0 and src_off % 4 == 0 and self._kernels:
             rc = _k().dtf_mbox_gather(self._h, int(src_off) * 4, dst.data_ptr(), n * 4,
-                                      torch.cuda.current_stream(self.device).cuda_stream)
+                                      stream_ptr if stream_ptr is not None
+                                      else torch.cuda.current_stream(self.device).cuda_stream)
             if rc:
                 raise RuntimeError("peer gather failed (%d)" % rc)
             return
@@ -247,14 +248,16 @@ class PeerRegion:
             self._tables.append(t)
         return t
 
-    def move_ranges(self, table: RangeTable, gather: bool, remote_base: int, local: torch.Tensor):
+    def move_ranges(self, table: RangeTable, gather: bool, remote_base: int, local: torch.Tensor,
+                    stream_ptr: Optional[int] = None):
         """Every range of ``table`` at once: ``local[local_off:+n] = region[peer][remote_base + remote_off:+n]`` when
         ``gather``, the other direction otherwise (GPU: one launch on the current stream, all peers in flight)."""
         if local.dtype != torch.float32 or not local.is_contiguous():
             raise ValueError("peer regions move contiguous float32 tensors")
         if table.handle and remote_base % 4 == 0:
             rc = _k().dtf_mbox_ranges_run(self._h, table.handle, 1 if gather else 0, int(remote_base) * 4, local.data_ptr(),
-                                          local.numel() * 4, torch.cuda.current_stream(self.device).cuda_stream)
+                                          local.numel() * 4, stream_ptr if stream_ptr is not None
+                                          else torch.cuda.current_stream(self.device).cuda_stream)
             if rc:
                 raise RuntimeError("peer range %s failed (%d)" % ("gather" if gather else "scatter", rc))
             return

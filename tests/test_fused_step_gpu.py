@@ -131,3 +131,37 @@ def test_async_workers_inside_the_gpu_share_the_variables(gpu_device):
     m.stats.zero_()
     m.train_steps_fused(xt, yt, 50, 3, plan, workers=8)
     assert m.global_step == 3603 and m.stats[2].item() == 150
+
+
+def test_fused_gradient_kernel_matches_the_layer_kernels(gpu_device):
+    """``dtf_mlp3_fused_grad`` (forward, loss and backward of one batch in one launch, what a cluster replica runs before
+    it hands its gradients to the strategy) against the layer-by-layer kernels: same gradients, same statistics, and
+    variables / step counter untouched.  Dropout on: both paths derive the masks from (seed, step, element)."""
+    import torch
+    from distributed_tensorflow_amd.data import get_data
+    from distributed_tensorflow_amd.models import xor_mlp
+    from distributed_tensorflow_amd.ops import functional as F
+    x, y = get_data(200, val_set_size=0, seed=3, device=gpu_device)[:2]
+    m = xor_mlp()
+    m.compile(loss="mean_squared_error", optimizer="adam", metrics=["binary_rounded_accuracy"], device=gpu_device, seed=5)
+    st = m.store
+    st.global_step.fill_(17)
+    eff = m._effective
+    offsets = [v.offset for l in eff for v in (l.kernel, l.bias)]
+    dims = (64, 128, 128, 32)
+    for B in (50, 64, 7):
+        xb, yb = x[:B].contiguous(), y[:B].contiguous()
+        m.stats.zero_()
+        m.compute_gradients(xb, yb)                     # LocalStrategy: the layer kernels
+        ref_grad, ref_stats = st.flat_grad.clone(), m.stats.clone()
+        flat0, step0 = st.flat.clone(), int(st.global_step.item())
+        grads = torch.full_like(st.flat_grad, float("nan"))
+        stats = torch.zeros_like(m.stats)
+        F.mlp3_fused_grad(xb, yb, st.flat, grads, offsets, dims, True, m._extra_categorical, eff[0].fused_keep,
+                          eff[1].fused_keep, eff[0].seed, eff[1].seed, st.global_step, stats)
+        for l in eff:
+            for v in (l.kernel, l.bias):
+                torch.testing.assert_close(grads[v.offset:v.offset + v.numel], ref_grad[v.offset:v.offset + v.numel],
+                                           rtol=2e-4, atol=2e-6, msg="%s at batch %d" % (v.name, B))
+        torch.testing.assert_close(stats[:3], ref_stats[:3], rtol=1e-4, atol=1e-5)
+        assert torch.equal(st.flat, flat0) and int(st.global_step.item()) == step0
