@@ -76,6 +76,18 @@ struct FusedArgs {
     unsigned int* ctl;   // MULTI: {elected XCD (0xFFFFFFFF = none yet), workers admitted, workgroups left, step tickets}
     int workers;         // MULTI: workgroups that may train at once
     int stagger;         // MULTI: worker number i starts i * stagger ticks of the 100 MHz wall clock late
+    // Gradient-only launches (OPT 2) of a worker whose variables live with parameter-server tasks: variable i is read
+    // from var_ptr[i] and its gradient written to grad_ptr[i] - peer-mapped memory of the owning task (its variable
+    // plane, this worker's inbox slot there) - and the launch ends by ringing the owners' doorbells, so a worker's
+    // whole step is this one kernel: no pull, no push, no copy.  Null pointers: params + off[i] / slot_m + off[i].
+    const float* var_ptr[6];
+    float* grad_ptr[6];
+    unsigned long long* ring_rep[64];        // every rank's replica of the control blocks, as this GPU addresses it
+    int ring_world, ring_self;               // number of replicas; the one in this rank's own memory
+    long long ring_block_word[8];            // owner i: position of its block inside a replica (64-bit words)
+    long long ring_lane_word[8];             // owner i: position of this worker's lane in that block, inside a replica
+    int ring_count, ring_slot;
+    unsigned long long ring_seq, ring_clock;
 };
 
 // Phase timestamp i of the launch's last step (thread 0 only; a scalar branch when profiling is off).
@@ -86,6 +98,9 @@ struct FusedArgs {
 
 __device__ __forceinline__ float ld1_sc1(const float* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ld1_sys(const float* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---- global -> register -> LDS staging -------------------------------------------------------
@@ -98,15 +113,16 @@ struct Stage {
     static_assert(NV * NT * 4 == ROWS * COLS, "block must split evenly over the workgroup");
     f32x4 v[NV];
 
-    // `ld`: row stride of the source in floats; SC1: L2-served load
-    template <bool SC1>
+    // `ld`: row stride of the source in floats; AUX: cache-policy bits of the load (0 plain, 16 = sc1: served by this
+    // GPU's L2, 17 = sc0 sc1: system scope, for variables that live in a peer's memory)
+    template <int AUX>
     __device__ __forceinline__ void issue(const float* base, unsigned bytes, int ld, int tid) {
         __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)bytes, 0x00020000);
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int idx = tid + NT * i;
             const int row = idx / (COLS / 4), c = (idx % (COLS / 4)) * 4;
-            const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(r, (row * ld + c) * 4, 0, SC1 ? 16 : 0);
+            const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(r, (row * ld + c) * 4, 0, AUX);
             v[i] = __builtin_bit_cast(f32x4, raw);
         }
     }
@@ -201,15 +217,15 @@ struct TileState {
     // apply the gradient tile; `mirror` (optional) receives the new values as an LDS image [rows][ldm]
     template <bool SHARED = false>
     __device__ __forceinline__ void finish(const VarBufs& vb, const Opt& o, const f32x16& g, long long off, int N, int i0,
-                                           int n0, int lane, float* mirror, int ldm) {
+                                           int n0, int lane, float* mirror, int ldm, float* gdst = nullptr) {
         const int li = lane & 31, h = lane >> 5;
         const int base = ((int)off + (i0 + 4 * h) * N + n0 + li) * 4;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int rr = (r & 3) + 8 * (r >> 2);
             const int bo = base + rr * N * 4;
-            if (OPT == 2) {             // gradients only: vb.m is the gradient buffer, the variables stay as they are
-                vb_store(vb.m, bo, g[r]);
+            if (OPT == 2) {             // gradients only: to the variable's gradient tensor, the variables stay as they are
+                gdst[(i0 + 4 * h + rr) * N + n0 + li] = g[r];
                 continue;
             }
             if (SHARED) {
@@ -249,7 +265,7 @@ struct BiasState {
     // `mirror`: LDS copy of the bias that the next step's forward epilogue reads
     template <bool SHARED = false>
     __device__ __forceinline__ void finish(const VarBufs& vb, const Opt& o, const float* dz, int ld, long long off, int N,
-                                           int tid, float* mirror) {
+                                           int tid, float* mirror, float* gdst = nullptr) {
         if (tid < N) {
             float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll 4
@@ -261,7 +277,7 @@ struct BiasState {
             }
             const int bo = ((int)off + tid) * 4;
             if (OPT == 2) {
-                vb_store(vb.m, bo, (s0 + s1) + (s2 + s3));
+                gdst[tid] = (s0 + s1) + (s2 + s3);
                 return;
             }
             if (SHARED) {
@@ -285,6 +301,7 @@ struct BiasState {
 
 template <int OPT, bool MULTI>
 __global__ __launch_bounds__(NT, 1) void mlp3_fused_kernel(const FusedArgs p) {
+    constexpr int WAUX = OPT == 2 ? 17 : 16;    // variable loads: a gradient-only launch may read them from a peer's memory
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* sX = lds;
     float* sY = sX + BM * LX;
@@ -335,9 +352,21 @@ __global__ __launch_bounds__(NT, 1) void mlp3_fused_kernel(const FusedArgs p) {
     const unsigned W_BYTES = 0x7FFFFFF0u;
     VarBufs vb;
     vb.w = __builtin_amdgcn_make_buffer_rsrc(p.params, 0, (int)W_BYTES, 0x00020000);
-    vb.m = __builtin_amdgcn_make_buffer_rsrc(OPT != 1 ? p.slot_m : p.params, 0, (int)W_BYTES, 0x00020000);   // OPT 2: gradients
+    vb.m = __builtin_amdgcn_make_buffer_rsrc(OPT == 0 ? p.slot_m : p.params, 0, (int)W_BYTES, 0x00020000);
     vb.v = __builtin_amdgcn_make_buffer_rsrc(OPT == 0 ? p.slot_v : p.params, 0, (int)W_BYTES, 0x00020000);
     vb.wptr = p.params;
+    // where each variable is read and (gradient-only launches) where its gradient goes
+    const float* vp[6];
+    float* gp[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        vp[k] = (OPT == 2 && p.var_ptr[k]) ? p.var_ptr[k] : p.params + p.off[k];
+        gp[k] = OPT == 2 ? (p.grad_ptr[k] ? p.grad_ptr[k] : p.slot_m + p.off[k]) : nullptr;
+    }
+    unsigned long long pulled_version = 0;
+    if (OPT == 2 && tid0 < p.ring_count)      // word 0 of owner tid0's block (this rank's replica): its version
+        pulled_version = __hip_atomic_load(p.ring_rep[p.ring_self] + p.ring_block_word[tid0], __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_SYSTEM);
 
     Stage<64, 128> pw;             // W1, a 64-row chunk of W2 (forward)
     Stage<128, 64> pt;             // a 64-column slice of W2 (dgrad)
@@ -346,13 +375,13 @@ __global__ __launch_bounds__(NT, 1) void mlp3_fused_kernel(const FusedArgs p) {
     Stage<BM, D3> py;
 
     if (worker) {
-    px.template issue<false>(p.X + (long long)ticket * B * D0, (unsigned)B * D0 * 4, D0, tid);
-    py.template issue<false>(p.Y + (long long)ticket * B * D3, (unsigned)B * D3 * 4, D3, tid);
-    pw.template issue<true>(p.params + p.off[0], W_BYTES, D1, tid);
+    px.template issue<0>(p.X + (long long)ticket * B * D0, (unsigned)B * D0 * 4, D0, tid);
+    py.template issue<0>(p.Y + (long long)ticket * B * D3, (unsigned)B * D3 * 4, D3, tid);
+    pw.template issue<WAUX>(vp[0], W_BYTES, D1, tid);
     pw.commit(sW, tid);            // W1 image; later steps of a lone worker find it already there
-    if (tid < D1) sB1[tid] = ld1_sc1(p.params + p.off[1] + tid);
-    if (tid < D2) sB2[tid] = ld1_sc1(p.params + p.off[3] + tid);
-    if (tid < D3) sB3[tid] = ld1_sc1(p.params + p.off[5] + tid);
+    if (tid < D1) sB1[tid] = OPT == 2 ? ld1_sys(vp[1] + tid) : ld1_sc1(vp[1] + tid);
+    if (tid < D2) sB2[tid] = OPT == 2 ? ld1_sys(vp[3] + tid) : ld1_sc1(vp[3] + tid);
+    if (tid < D3) sB3[tid] = OPT == 2 ? ld1_sys(vp[5] + tid) : ld1_sc1(vp[5] + tid);
 
     for (int s = MULTI ? ticket : 0; s >= 0 && s < p.nsteps;) {
         // The thread index is made opaque once per step: every address and dropout-hash term below is step-invariant,
@@ -383,7 +412,7 @@ __global__ __launch_bounds__(NT, 1) void mlp3_fused_kernel(const FusedArgs p) {
         const float bf1 = sB1[col], bf2 = sB2[col], bf3 = sB3[tid & 31];
 
         // ---- L1: h1 = dropout(relu(x W1 + b1))
-        pw.template issue<true>(p.params + p.off[2], W_BYTES, D2, tid);                 // W2 rows 0..63
+        pw.template issue<WAUX>(vp[2], W_BYTES, D2, tid);                 // W2 rows 0..63
         {
             f32x16 acc; zero(acc);
             tile_mma<true, false, D0>(acc, sX, LX, tm * 32, sW, L1, tn * 32, lane);
@@ -399,14 +428,14 @@ __global__ __launch_bounds__(NT, 1) void mlp3_fused_kernel(const FusedArgs p) {
         DTF_PROF(2);
         // ---- L2: h2 = dropout(relu(h1 W2 + b2)); two k-chunks of 64
         pw.commit(sW, tid);
-        pw.template issue<true>(p.params + p.off[2] + 64 * D2, W_BYTES, D2, tid);       // W2 rows 64..127
+        pw.template issue<WAUX>(vp[2] + 64 * D2, W_BYTES, D2, tid);       // W2 rows 64..127
         __syncthreads();
         f32x16 acc2; zero(acc2);
         tile_mma<true, false, 64>(acc2, sH1, L1, tm * 32, sW, L2, tn * 32, lane);
         __syncthreads();
         DTF_PROF(3);
         pw.commit(sW, tid);
-        pw3.template issue<true>(p.params + p.off[4], W_BYTES, D3, tid);                // W3
+        pw3.template issue<WAUX>(vp[4], W_BYTES, D3, tid);                // W3
         __syncthreads();
         tile_mma<true, false, 64>(acc2, sH1 + 64, L1, tm * 32, sW, L2, tn * 32, lane);
 #pragma unroll
@@ -483,7 +512,7 @@ __global__ __launch_bounds__(NT, 1) void mlp3_fused_kernel(const FusedArgs p) {
         bs3.issue(vb, p.off[5], D3, tid);
         bs2.issue(vb, p.off[3], D2, tid);
         bs1.issue(vb, p.off[1], D1, tid);
-        pt.template issue<true>(p.params + p.off[2], W_BYTES, D2, tid);                 // W2 columns 0..63
+        pt.template issue<WAUX>(vp[2], W_BYTES, D2, tid);                 // W2 columns 0..63
         f32x16 g3; zero(g3);
         if (wave < 4) tile_mma<false, false, BM>(g3, sH2, L2, wave * 32, sP, L3, 0, lane);
         f32x16 az; zero(az);
@@ -503,9 +532,9 @@ __global__ __launch_bounds__(NT, 1) void mlp3_fused_kernel(const FusedArgs p) {
         // ---- dW2 = h1^T dz2 held in registers: tiles t = wave, wave + 8 (input block t >> 2, output block t & 3).
         //      Waves 0..3 first apply W3 / b3 (VALU + memory) while their SIMD partners 4..7 already run MFMAs.
         pt.commit(sW, tid);
-        pt.template issue<true>(p.params + p.off[2] + 64, W_BYTES, D2, tid);            // W2 columns 64..127
-        if (wave < 4) ts.template finish<MULTI>(vb, o, g3, p.off[4], D3, wave * 32, 0, lane, nullptr, 0);
-        bs3.template finish<MULTI>(vb, o, sP, L3, p.off[5], D3, tid, sB3);
+        pt.template issue<WAUX>(vp[2] + 64, W_BYTES, D2, tid);            // W2 columns 64..127
+        if (wave < 4) ts.template finish<MULTI>(vb, o, g3, p.off[4], D3, wave * 32, 0, lane, nullptr, 0, gp[4]);
+        bs3.template finish<MULTI>(vb, o, sP, L3, p.off[5], D3, tid, sB3, gp[5]);
         f32x16 g2[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -513,7 +542,7 @@ __global__ __launch_bounds__(NT, 1) void mlp3_fused_kernel(const FusedArgs p) {
             const int t = wave + 8 * q;
             tile_mma<false, false, BM>(g2[q], sH1, L1, (t >> 2) * 32, sH2, L2, (t & 3) * 32, lane);
         }
-        bs2.template finish<MULTI>(vb, o, sH2, L2, p.off[3], D2, tid, sB2);
+        bs2.template finish<MULTI>(vb, o, sH2, L2, p.off[3], D2, tid, sB2, gp[3]);
         __syncthreads();                                                                // h1 readers done; slice 0 visible
         DTF_PROF(9);
         // ---- dz1 = (dz2 W2^T) * (h1 > 0) / keep1 in place of h1, summed over two 64-wide slices of W2's columns
@@ -538,8 +567,8 @@ __global__ __launch_bounds__(NT, 1) void mlp3_fused_kernel(const FusedArgs p) {
         //      so one's update arithmetic and memory traffic overlap the other's MFMAs.
         const int next = MULTI ? sTicket[1] : s + 1;       // (written several barriers ago)
         if (next < p.nsteps) {
-            px.template issue<false>(p.X + (long long)next * B * D0, (unsigned)B * D0 * 4, D0, tid);
-            py.template issue<false>(p.Y + (long long)next * B * D3, (unsigned)B * D3 * 4, D3, tid);
+            px.template issue<0>(p.X + (long long)next * B * D0, (unsigned)B * D0 * 4, D0, tid);
+            py.template issue<0>(p.Y + (long long)next * B * D3, (unsigned)B * D3 * 4, D3, tid);
         }
         {
             const int i2a = (wave >> 2) * 32, i2b = ((wave + 8) >> 2) * 32, n2 = (wave & 3) * 32;
@@ -547,25 +576,25 @@ __global__ __launch_bounds__(NT, 1) void mlp3_fused_kernel(const FusedArgs p) {
             if (wave < 4) {
                 t2.issue(vb, p.off[2], D2, i2a, n2, lane);
                 t1.issue(vb, p.off[0], D1, tm * 32, tn * 32, lane);
-                t2.template finish<MULTI>(vb, o, g2[0], p.off[2], D2, i2a, n2, lane, nullptr, 0);
+                t2.template finish<MULTI>(vb, o, g2[0], p.off[2], D2, i2a, n2, lane, nullptr, 0, gp[2]);
                 t2.issue(vb, p.off[2], D2, i2b, n2, lane);
                 f32x16 acc; zero(acc);
                 tile_mma<false, false, BM>(acc, sX, LX, tm * 32, sH1, L1, tn * 32, lane);
-                t2.template finish<MULTI>(vb, o, g2[1], p.off[2], D2, i2b, n2, lane, nullptr, 0);
-                t1.template finish<MULTI>(vb, o, acc, p.off[0], D1, tm * 32, tn * 32, lane, sW, L1);
+                t2.template finish<MULTI>(vb, o, g2[1], p.off[2], D2, i2b, n2, lane, nullptr, 0, gp[2]);
+                t1.template finish<MULTI>(vb, o, acc, p.off[0], D1, tm * 32, tn * 32, lane, sW, L1, gp[0]);
             } else {
                 t1.issue(vb, p.off[0], D1, tm * 32, tn * 32, lane);
                 t2.issue(vb, p.off[2], D2, i2a, n2, lane);
                 f32x16 acc; zero(acc);
                 tile_mma<false, false, BM>(acc, sX, LX, tm * 32, sH1, L1, tn * 32, lane);
-                t2.template finish<MULTI>(vb, o, g2[0], p.off[2], D2, i2a, n2, lane, nullptr, 0);
+                t2.template finish<MULTI>(vb, o, g2[0], p.off[2], D2, i2a, n2, lane, nullptr, 0, gp[2]);
                 t2.issue(vb, p.off[2], D2, i2b, n2, lane);
-                t1.template finish<MULTI>(vb, o, acc, p.off[0], D1, tm * 32, tn * 32, lane, sW, L1);
-                t2.template finish<MULTI>(vb, o, g2[1], p.off[2], D2, i2b, n2, lane, nullptr, 0);
+                t1.template finish<MULTI>(vb, o, acc, p.off[0], D1, tm * 32, tn * 32, lane, sW, L1, gp[0]);
+                t2.template finish<MULTI>(vb, o, g2[1], p.off[2], D2, i2b, n2, lane, nullptr, 0, gp[2]);
             }
         }
         DTF_PROF(11);
-        bs1.template finish<MULTI>(vb, o, sH1, L1, p.off[1], D1, tid, sB1);
+        bs1.template finish<MULTI>(vb, o, sH1, L1, p.off[1], D1, tid, sB1, gp[1]);
         // every wave's variable stores must have reached L2 before the next step requests them again
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -575,11 +604,11 @@ __global__ __launch_bounds__(NT, 1) void mlp3_fused_kernel(const FusedArgs p) {
             // other workers have updated the variables meanwhile: W1 and the biases come from L2 again (the other
             // weights are streamed every step anyway); the barrier at the top of the next step publishes the images
             if (next < p.nsteps) {
-                pw.template issue<true>(p.params + p.off[0], W_BYTES, D1, tid);
+                pw.template issue<WAUX>(vp[0], W_BYTES, D1, tid);
                 pw.commit(sW, tid);
-                if (tid < D1) sB1[tid] = ld1_sc1(p.params + p.off[1] + tid);
-                if (tid < D2) sB2[tid] = ld1_sc1(p.params + p.off[3] + tid);
-                if (tid < D3) sB3[tid] = ld1_sc1(p.params + p.off[5] + tid);
+                if (tid < D1) sB1[tid] = ld1_sc1(vp[1] + tid);
+                if (tid < D2) sB2[tid] = ld1_sc1(vp[3] + tid);
+                if (tid < D3) sB3[tid] = ld1_sc1(vp[5] + tid);
             }
             s = next;
         } else {
@@ -587,6 +616,24 @@ __global__ __launch_bounds__(NT, 1) void mlp3_fused_kernel(const FusedArgs p) {
         }
     }
     }   // worker
+
+    // ---- gradient-only launch of a parameter-server worker: every gradient store has left this CU; tell the owners
+    if (OPT == 2 && p.ring_count > 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __threadfence_system();
+        __syncthreads();
+        if (tid0 < p.ring_count) {      // thread i rings owner i, in every replica: pull_version[slot], clock, then the door
+            const long long lw = p.ring_lane_word[tid0];
+            for (int r = 0; r < p.ring_world; ++r) {
+                unsigned long long* ln = p.ring_rep[r] + lw;
+                __hip_atomic_store(ln + 2 + p.ring_slot, pulled_version, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (tid0 == 0) __hip_atomic_store(ln + 1, p.ring_clock, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            __threadfence_system();
+            for (int r = 0; r < p.ring_world; ++r)
+                __hip_atomic_store(p.ring_rep[r] + lw, p.ring_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 
     // ---- once per launch: statistics, global_step, beta powers
     const int lane = tid0 & 63, wave = tid0 >> 6;
@@ -741,5 +788,51 @@ DTF_API int dtf_mlp3_fused_grad(const float* X, const float* Y, const float* par
     a.lr = 0.f; a.beta1 = 0.9f; a.beta2 = 0.999f; a.eps = 1e-8f;
     a.step_ptr = const_cast<long long*>(step_ptr); a.beta_powers = nullptr; a.stats = stats; a.prof = nullptr;
     a.ctl = nullptr; a.workers = 1;
+    return launch_fused(a, 2, stream);
+}
+
+
+// The same for a worker whose variables live with parameter-server tasks: variable i is read from var_ptr6[i], its
+// gradient goes to grad_ptr6[i] (both peer-mapped memory of the owning task), `step_ptr` is the shared global step as
+// the GPU addresses it, and the launch ends by publishing gradient number `seq` (inbox slot `slot`) to `count` <= 8
+// owners (count == 0: the caller rings the doorbells behind this launch): `replicas` are the control areas of all
+// `world` ranks as this GPU addresses them, `self_rank` the one in this rank's own memory, `block_words[i]` /
+// `lane_words[i]` the positions of owner i's block and of this worker's lane in it inside an area.  The owners'
+// version words are read when the launch starts (what the gradient counts as computed from); `clock` goes to owner
+// 0's block.
+DTF_API int dtf_mlp3_fused_grad_direct(const float* X, const float* Y, const void* const* var_ptr6, void* const* grad_ptr6,
+                                       int d0, int d1, int d2, int d3, int B, int training, int want_cat, float keep1,
+                                       float keep2, uint32_t seed1, uint32_t seed2, const long long* step_ptr, float* stats,
+                                       void* const* replicas, int world, int self_rank, const long long* block_words,
+                                       const long long* lane_words, int count, int slot, unsigned long long seq,
+                                       unsigned long long clock, hipStream_t stream) {
+    if (!dtf_mlp3_fused_supported(d0, d1, d2, d3, B)) return -4;
+    if (!var_ptr6 || !grad_ptr6 || !step_ptr || count < 0 || count > 8 || slot < 0 || slot > 3) return -5;
+    if (count > 0 && (!replicas || world < 1 || world > 64 || self_rank < 0 || self_rank >= world || !block_words || !lane_words))
+        return -5;
+    FusedArgs a = {};
+    a.X = X; a.Y = Y;
+    for (int i = 0; i < 6; ++i) {
+        if (!var_ptr6[i] || !grad_ptr6[i]) return -5;
+        a.var_ptr[i] = static_cast<const float*>(var_ptr6[i]);
+        a.grad_ptr[i] = static_cast<float*>(grad_ptr6[i]);
+    }
+    if (count > 0) {
+        for (int r = 0; r < world; ++r) {
+            if (!replicas[r]) return -5;
+            a.ring_rep[r] = static_cast<unsigned long long*>(replicas[r]);
+        }
+        a.ring_world = world; a.ring_self = self_rank;
+        for (int i = 0; i < count; ++i) {
+            a.ring_block_word[i] = block_words[i];
+            a.ring_lane_word[i] = lane_words[i];
+        }
+    }
+    a.ring_count = count; a.ring_slot = slot; a.ring_seq = seq; a.ring_clock = clock;
+    a.B = B; a.nsteps = 1; a.training = training; a.want_cat = want_cat;
+    a.keep1 = keep1; a.keep2 = keep2; a.seed1 = seed1; a.seed2 = seed2;
+    a.lr = 0.f; a.beta1 = 0.9f; a.beta2 = 0.999f; a.eps = 1e-8f;
+    a.step_ptr = const_cast<long long*>(step_ptr); a.stats = stats;
+    a.workers = 1;
     return launch_fused(a, 2, stream);
 }

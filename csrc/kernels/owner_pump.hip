@@ -16,13 +16,16 @@
 //   (before reusing inbox[w][(t+D) % D]:                        ctl.version, ctl.global_step, lane[w].ack = t + 1
 //    wait until lane[w].ack > t)
 //
-// The words live in host memory shared by all processes of the node (one control block per owner).  On GPUs every
-// process registers the blocks with the HIP runtime, and the words are written by one-workgroup kernels queued right
-// behind the copies / the apply kernel on the same stream (stream order: the data is complete when the word changes;
-// the stores are system-scope releases into coherent host memory) - no host callback sits between a gradient's
-// arrival and its apply, or between the apply and its acknowledgement.  Without registered blocks
-// (DTF_DOORBELL_KERNELS=0) the same words are written by stream host functions instead.  The gradient and parameter
-// data itself stays in device memory (peer-mapped regions, see peer_mailbox.hip).
+// Where the words live.  On GPUs whose memory the CPU can address (large BAR: every MI355X) each rank keeps a replica
+// of all control blocks at the end of its peer region, in ITS OWN device memory: a CPU reads words only from the
+// replica of its own process (the CPU cannot address memory mapped from another process's hipIpc handle, and the
+// runtime does not register POSIX shared memory for GPU access), and every word is written by a one-workgroup kernel
+// that stores it into all replicas through the peer mappings - queued right behind the copies / the apply kernel on
+// the same stream (stream order: the data is complete when the word changes; system-scope release stores).  No host
+// callback sits between a gradient's arrival and its apply, or between the apply and its acknowledgement.
+// Otherwise (CPUs; DTF_DOORBELL_KERNELS=0) the blocks are POSIX shared memory and the words are written by host code:
+// directly on a CPU, from stream host functions on a GPU.  The gradient and parameter data itself stays in device
+// memory (peer-mapped regions, see peer_mailbox.hip).
 //
 // On a CPU (the plumbing configuration and the tests) the same thread applies the update itself and the doorbell is
 // a plain store.
@@ -79,8 +82,13 @@ struct Config {
     unsigned int* ticket;
     float lr, b1, b2, eps, momentum;
     int pad2;
-    void* ctl;
-    void* ctl_dev;                              // the control block as the GPU addresses it (registered host memory), or null
+    void* ctl;                                  // this owner's control block as this process's CPU addresses it
+    // replica mode (rep_world > 0): the control areas of all ranks as this GPU addresses them, and the position of this
+    // owner's block inside an area (in 64-bit words); acknowledgements are stored into every replica by a kernel
+    void* rep_base[64];
+    int rep_world;
+    int pad3;
+    long long block_word;
 };
 
 struct Pump;
@@ -115,38 +123,64 @@ __device__ __forceinline__ void word_release(unsigned long long* p, unsigned lon
     __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// Owner: the apply queued before this launch on the same stream is complete.  One thread per word (addresses come
-// from the thread index: vector stores), the acknowledgement itself last.
-__global__ __launch_bounds__(64) void ack_kernel(unsigned long long* ctl, int worker, int slot, unsigned long long seq,
+struct Replicas {
+    unsigned long long* base[64];       // the control area of every rank, as this GPU addresses it
+    int world;
+};
+
+// Owner: the apply queued before this launch on the same stream is complete.  Thread r writes replica r (addresses
+// come from the thread index: vector stores), the acknowledgement itself last.
+__global__ __launch_bounds__(64) void ack_kernel(Replicas reps, long long block_word, int worker, int slot, unsigned long long seq,
                                                  unsigned long long version, unsigned long long gstep, int owner0) {
-    unsigned long long* lane = ctl + 16 + 16 * worker;
-    const int t = threadIdx.x;
-    if (t == 0) word_store(lane + W_ACKV + slot, version);
-    if (t == 1) word_store(ctl + W_VERSION, version);
-    if (t == 2 && owner0) word_store(ctl + W_GSTEP, gstep);
-    __threadfence_system();
-    __syncthreads();
-    if (t == 0) word_release(lane + W_ACK, seq);
+    const int r = threadIdx.x;
+    if (r < reps.world) {
+        unsigned long long* ctl = reps.base[r] + block_word;
+        unsigned long long* lane = ctl + 16 + 16 * worker;
+        word_store(lane + W_ACKV + slot, version);
+        word_store(ctl + W_VERSION, version);
+        if (owner0) word_store(ctl + W_GSTEP, gstep);
+        __threadfence_system();
+        word_release(lane + W_ACK, seq);
+    }
 }
 
 struct RingArgs {
-    unsigned long long* lane[64];
+    long long lane_word[64];            // owner i: position of this worker's lane in owner i's block, inside a control area
     unsigned long long pulled[64];
     int count, slot;
     unsigned long long seq, clock;
 };
 
 // Worker: everything queued before this launch on the same stream (the gradient shards in the owners' inboxes) is
-// complete.  Thread i rings owner i.
-__global__ __launch_bounds__(64) void ring_kernel(RingArgs a) {
+// complete.  Thread i rings owner i, in every replica.
+__global__ __launch_bounds__(64) void ring_kernel(Replicas reps, RingArgs a) {
     const int i = threadIdx.x;
     if (i < a.count) {
-        unsigned long long* lane = a.lane[i];
-        word_store(lane + W_PULLV + a.slot, a.pulled[i]);
-        if (i == 0) word_store(lane + W_CLOCK, a.clock);      // lane[0] belongs to owner 0's block
+        for (int r = 0; r < reps.world; ++r) {
+            unsigned long long* lane = reps.base[r] + a.lane_word[i];
+            word_store(lane + W_PULLV + a.slot, a.pulled[i]);
+            if (i == 0) word_store(lane + W_CLOCK, a.clock);      // lane_word[0] lies in owner 0's block
+        }
         __threadfence_system();
-        word_release(lane + W_DOOR, a.seq);
+        for (int r = 0; r < reps.world; ++r) word_release(reps.base[r] + a.lane_word[i] + W_DOOR, a.seq);
     }
+}
+
+// One word of the control area, the same value into every replica (the rare updates host code makes: a finished
+// worker's clock, a re-based step, a restarted worker's lane).
+__global__ __launch_bounds__(64) void word_kernel(Replicas reps, long long word, unsigned long long value) {
+    const int r = threadIdx.x;
+    if (r < reps.world) word_release(reps.base[r] + word, value);
+}
+
+bool fill_replicas(Replicas& reps, void* const* bases, int world) {
+    if (!bases || world < 1 || world > 64) return false;
+    reps.world = world;
+    for (int r = 0; r < world; ++r) {
+        if (!bases[r]) return false;
+        reps.base[r] = static_cast<unsigned long long*>(bases[r]);
+    }
+    return true;
 }
 
 void acknowledge(const AckRecord& r) {
@@ -233,7 +267,7 @@ void pump_loop(Pump* p, int device) {
             const int slot = (int)(seq % (uint64_t)c.depth);
             const float* g = c.inbox + ((long long)w * c.depth + slot) * c.slot_stride;
             AckRecord rec{p, w, slot, seq + 1, ++p->enqueued_version, lane.pull_version[slot]};
-            if (c.on_gpu && c.ctl_dev) {
+            if (c.on_gpu && c.rep_world > 0) {
                 // acknowledged by a kernel behind the apply; the applies of this owner are serial, so the version this
                 // one will leave behind - and with it the staleness of the gradient - is known now
                 int rc = gpu_apply(p, g);
@@ -242,7 +276,9 @@ void pump_loop(Pump* p, int device) {
                     uint64_t st = before > rec.pulled ? before - rec.pulled : 0;
                     if (st >= (uint64_t)PUMP_HIST) st = PUMP_HIST - 1;
                     p->hist[st].fetch_add(1, std::memory_order_relaxed);
-                    hipLaunchKernelGGL(ack_kernel, dim3(1), dim3(64), 0, p->stream, static_cast<unsigned long long*>(c.ctl_dev), w,
+                    Replicas reps;
+                    (void)fill_replicas(reps, c.rep_base, c.rep_world);
+                    hipLaunchKernelGGL(ack_kernel, dim3(1), dim3(64), 0, p->stream, reps, c.block_word, w,
                                        slot, (unsigned long long)rec.seq, (unsigned long long)rec.version,
                                        (unsigned long long)(p->ctl->gs_base.load(std::memory_order_relaxed) + rec.version),
                                        c.owner == 0 ? 1 : 0);
@@ -385,26 +421,29 @@ DTF_API int dtf_pump_stop(void* h) {
 }
 
 // Worker side: after everything queued on `stream` so far (the puts of this step's gradient shards), tell `count`
-// owners that gradient number `seq` (1-based) of this worker is complete in slot `slot` of their inboxes.
-// `lanes[i]` is this worker's lane in owner i's control block, `pulled[i]` the owner version the gradient was
-// computed from.  `clock` is published in lanes[0] (owner 0's block) for the staleness bound.  `lanes_dev` (GPU
-// only, may be null): the same lanes as the GPU addresses them - the words are then written by a kernel on `stream`;
-// otherwise by a host function on it.  stream == null on a CPU: the stores happen now.
-DTF_API int dtf_doorbell_ring(hipStream_t stream, int on_gpu, void* const* lanes, void* const* lanes_dev,
-                              const unsigned long long* pulled, int count, int slot, unsigned long long seq,
-                              unsigned long long clock) {
+// owners that gradient number `seq` (1-based) of this worker is complete in slot `slot` of their inboxes; `pulled[i]`
+// is the owner version the gradient was computed from; `clock` is published in owner 0's block for the staleness
+// bound.  Two forms: `replicas` != null (GPU, replica mode) - the control areas of all `world` ranks as this GPU
+// addresses them, `lane_words[i]` the position of this worker's lane in owner i's block inside an area: a kernel on
+// `stream` stores the words into every replica.  Otherwise `lanes[i]` is the lane in owner i's shared-memory block:
+// a host function on `stream` writes it (stream == null on a CPU: the stores happen now).
+DTF_API int dtf_doorbell_ring(hipStream_t stream, int on_gpu, void* const* lanes, void* const* replicas, int world,
+                              const long long* lane_words, const unsigned long long* pulled, int count, int slot,
+                              unsigned long long seq, unsigned long long clock) {
     if (count < 1 || count > 64 || slot < 0 || slot >= PUMP_MAX_DEPTH) return -2;
-    if (on_gpu && lanes_dev) {
+    if (on_gpu && replicas) {
+        Replicas reps;
+        if (!fill_replicas(reps, replicas, world) || !lane_words) return -2;
         RingArgs a;
         a.count = count; a.slot = slot; a.seq = seq; a.clock = clock;
         for (int i = 0; i < count; ++i) {
-            if (!lanes_dev[i]) return -2;
-            a.lane[i] = static_cast<unsigned long long*>(lanes_dev[i]);
+            a.lane_word[i] = lane_words[i];
             a.pulled[i] = pulled[i];
         }
-        hipLaunchKernelGGL(ring_kernel, dim3(1), dim3(64), 0, stream, a);
+        hipLaunchKernelGGL(ring_kernel, dim3(1), dim3(64), 0, stream, reps, a);
         return (int)hipGetLastError();
     }
+    if (!lanes) return -2;
     auto* r = new RingRecord();
     r->count = count;
     r->slot = slot;
@@ -427,18 +466,26 @@ DTF_API int dtf_doorbell_ring(hipStream_t stream, int on_gpu, void* const* lanes
     return 0;
 }
 
-// Host memory shared between processes (the control blocks) made addressable by this process's GPU: returns the device
-// alias through `dev_out`.  The mapping is coherent: a GPU store is seen by a polling CPU thread of any process.
-DTF_API int dtf_host_register(void* host, long long bytes, void** dev_out) {
-    if (!host || bytes <= 0 || !dev_out) return -2;
-    hipError_t e = hipHostRegister(host, (size_t)bytes, hipHostRegisterMapped | hipHostRegisterPortable);
-    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
-    e = hipHostGetDevicePointer(dev_out, host, 0);
-    if (e != hipSuccess) { (void)hipGetLastError(); (void)hipHostUnregister(host); return (int)e; }
-    return 0;
+// Replica mode: store `value` into 64-bit word `word` of every rank's control area, on `stream` (null stream allowed).
+DTF_API int dtf_words_broadcast(void* const* replicas, int world, long long word, unsigned long long value, hipStream_t stream) {
+    Replicas reps;
+    if (!fill_replicas(reps, replicas, world) || word < 0) return -2;
+    hipLaunchKernelGGL(word_kernel, dim3(1), dim3(64), 0, stream, reps, word, value);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    return (int)e;
 }
 
-DTF_API int dtf_host_unregister(void* host) { return host ? (int)hipHostUnregister(host) : 0; }
+// 1 when this process's CPU can address the current device's memory (large BAR): what the replica mode needs.
+DTF_API int dtf_device_large_bar() {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return prop.isLargeBar ? 1 : 0;
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // A worker's link to its owners: the communication stream and the two events of the push choreography, so that one
@@ -485,9 +532,9 @@ DTF_API void* dtf_link_stream(void* h) { return static_cast<Link*>(h)->comm; }
 // (ps tasks as owners); else shard j of `grad` (shard_bytes each) goes to offset `remote_base` of rank j's region
 // (owners colocated with the workers).  Offsets in bytes.  Everything is queued; nothing waits on the host.
 DTF_API int dtf_link_push(void* link, void* mbox, void* table, hipStream_t cur, const void* grad, long long grad_bytes,
-                          long long remote_base, long long shard_bytes, void* const* lanes, void* const* lanes_dev,
-                          const unsigned long long* pulled, int count, int slot, unsigned long long seq,
-                          unsigned long long clock) {
+                          long long remote_base, long long shard_bytes, void* const* lanes, void* const* replicas, int world,
+                          const long long* lane_words, const unsigned long long* pulled, int count, int slot,
+                          unsigned long long seq, unsigned long long clock) {
     auto* l = static_cast<Link*>(link);
     if (!l || !mbox || !grad) return -2;
     hipError_t e = hipEventRecord(l->ev_grad, cur);
@@ -498,7 +545,7 @@ DTF_API int dtf_link_push(void* link, void* mbox, void* table, hipStream_t cur, 
     if (rc) return rc;
     e = hipEventRecord(l->ev_copied, l->comm);
     if (e != hipSuccess) return (int)e;
-    rc = dtf_doorbell_ring(l->comm, 1, lanes, lanes_dev, pulled, count, slot, seq, clock);
+    rc = dtf_doorbell_ring(l->comm, 1, lanes, replicas, world, lane_words, pulled, count, slot, seq, clock);
     if (rc) return rc;
     return (int)hipStreamWaitEvent(cur, l->ev_copied, 0);     // the next backward pass may overwrite the gradient buffer
 }

@@ -214,6 +214,13 @@ DTF_API long long dtf_mbox_bytes(void* h) { return (long long)static_cast<Mailbo
 // Device pointer of the local region (the Python side wraps it as a tensor).
 DTF_API void* dtf_mbox_local_ptr(void* h) { return static_cast<Mailbox*>(h)->local; }
 
+// Rank r's region as this process's kernels address it (null until it is mapped): kernels that read a peer's
+// variables or write into its inbox directly take their pointers from here.
+DTF_API void* dtf_mbox_peer_ptr(void* h, int r) {
+    auto* m = static_cast<Mailbox*>(h);
+    return (r >= 0 && r < m->world) ? m->peer[r] : nullptr;
+}
+
 DTF_API int dtf_mbox_local_handle(void* h, void* out_handle) {
     auto* m = static_cast<Mailbox*>(h);
     hipIpcMemHandle_t ipc;

@@ -217,6 +217,9 @@ class Sequential:
 
     # ------------------------------------------------------------------ execution pieces
     def forward(self, x: torch.Tensor, training: bool = False) -> torch.Tensor:
+        fresh = getattr(self.strategy, "ensure_fresh", None)
+        if fresh is not None:
+            fresh(self)      # a worker whose last steps read the parameter servers' memory directly: refresh its copy
         h = x
         for layer in self.layers:
             h = layer.forward(h, training)
@@ -331,6 +334,9 @@ class Sequential:
 
     def compute_gradients(self, x, y, stats: Optional[torch.Tensor] = None):
         """Forward + loss + backward: leaves dL/dvar in ``store.flat_grad`` (no variable update)."""
+        fresh = getattr(self.strategy, "ensure_fresh", None)
+        if fresh is not None:
+            fresh(self)
         if x.is_cuda and x.dim() == 2 and y.dim() == 2 and y.dtype == torch.float32 and x.shape[0] <= 64:
             gp = self.fused_grad_plan(int(x.shape[0]))
             if gp is not None:
@@ -348,6 +354,10 @@ class Sequential:
 
     def train_step(self, x: torch.Tensor, y: torch.Tensor):
         """One optimisation step on a device-resident batch; returns nothing (no host sync)."""
+        direct = getattr(self.strategy, "train_step_direct", None)
+        if direct is not None and direct(self, x, y):      # a parameter-server worker's step as one kernel
+            self._host_step += 1
+            return
         self.compute_gradients(x, y)
         self.strategy.apply_gradients(self)
         self._host_step += 1

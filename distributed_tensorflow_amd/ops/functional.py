@@ -556,6 +556,39 @@ def mlp3_fused_grad(x, y, params, grads, offsets, dims, training, want_cat, keep
     nv.check(rc, "dtf_mlp3_fused_grad")
 
 
+def mlp3_fused_grad_direct(x, y, var_ptrs, grad_ptrs, dims, training, want_cat, keep1, keep2, seed1, seed2, step_address,
+                           stats, blocks, worker, owners, slot, seq, clock):
+    """A parameter-server worker's whole step in one launch: the reference MLP's variables are read from
+    ``var_ptrs`` (six device addresses in peer-mapped memory of the owning ps tasks), the gradients written to
+    ``grad_ptrs`` (this worker's inbox slots there), and - with ``blocks`` (a ``ControlBlocks`` in replica mode) - the
+    kernel ends by ringing the doorbells of owners ``0 .. owners-1`` for worker ``worker`` itself; ``blocks=None``:
+    the caller rings them behind this launch.  ``step_address``: device address of the global step.  GPU only;
+    batch <= 64."""
+    import ctypes as C
+    nv.require_f32_contig(x, y)
+    if not x.is_cuda:
+        raise ValueError("the fused gradient kernel runs on the GPU only")
+    batch = int(x.shape[0])
+    if y.shape[0] != batch or x.shape[1] != dims[0] or y.shape[1] != dims[3]:
+        raise ValueError("fused gradients: batch %s/%s does not match %s" % (tuple(x.shape), tuple(y.shape), (dims[0], dims[3])))
+    if len(var_ptrs) != 6 or len(grad_ptrs) != 6 or not all(var_ptrs) or not all(grad_ptrs) or not step_address:
+        raise ValueError("fused gradients: six variables, no null device address")
+    n = int(owners) if blocks is not None else 0
+    if n > 8 or (blocks is not None and blocks.replicas is None):
+        raise ValueError("fused gradients: in-kernel doorbells need replica-mode control blocks and at most eight owners")
+    fn = nv.declare(nv.kernels(), "dtf_mlp3_fused_grad_direct",
+                    [nv.c_p] * 4 + [nv.c_i] * 7 + [nv.c_f, nv.c_f, nv.c_u32, nv.c_u32] + [nv.c_p] * 3
+                    + [nv.c_i, nv.c_i, nv.c_p, nv.c_p, nv.c_i, nv.c_i, C.c_ulonglong, C.c_ulonglong, nv.c_p])
+    bw = (C.c_longlong * n)(*[blocks.block_word(j) for j in range(n)]) if n else None
+    lw = (C.c_longlong * n)(*[blocks.lane_word(j, worker) for j in range(n)]) if n else None
+    rc = fn(nv.ptr(x), nv.ptr(y), (C.c_void_p * 6)(*var_ptrs), (C.c_void_p * 6)(*grad_ptrs), int(dims[0]), int(dims[1]),
+            int(dims[2]), int(dims[3]), batch, int(bool(training)), int(bool(want_cat)), float(keep1), float(keep2),
+            int(seed1) & _M32, int(seed2) & _M32, C.c_void_p(step_address), nv.ptr(stats),
+            blocks._rep_array if n else None, blocks.world if n else 0, blocks.rank if n else 0, bw, lw, n, int(slot),
+            int(seq), int(clock), nv.stream_ptr())
+    nv.check(rc, "dtf_mlp3_fused_grad_direct")
+
+
 # ----------------------------------------------------------------------------- convolution support (NHWC)
 def conv_geometry(H, W, KH, KW, strides=(1, 1), padding="valid"):
     """Output size and top/left zero padding, TensorFlow rules ('same': out = ceil(in / stride), extra padding goes

@@ -134,10 +134,12 @@ def _unpack(buf: torch.Tensor, flat: torch.Tensor, ranges):
         pos += e - b
 
 
-def region_sizes(stride: int, depth: int, num_ps: int, num_workers: int) -> List[int]:
+def region_sizes(stride: int, depth: int, num_ps: int, num_workers: int, area: int = 0) -> List[int]:
     """Floats per rank of the peer regions of a cluster whose ps tasks are the owners (ranks: ps tasks, then workers):
-    variables + two slot planes + ``depth`` inbox slots per worker on a ps task, a token allocation on a worker."""
-    return [3 * stride + num_workers * depth * stride] * num_ps + [64] * num_workers
+    variables + two slot planes + ``depth`` inbox slots per worker on a ps task, a token allocation on a worker; every
+    rank ends with ``area`` floats for its replica of the control blocks (``ControlBlocks.area_floats``; 0: the
+    blocks live in shared memory)."""
+    return [3 * stride + num_workers * depth * stride + area] * num_ps + [64 + area] * num_workers
 
 
 _LOOPBACK = {"localhost", "127.0.0.1", "0.0.0.0", "::1"}
@@ -337,12 +339,13 @@ class ParameterServerService:
         srv = self.server
         world = self.num_owners + self.num_workers
         self.depth = int(layout["depth"])
-        sizes = region_sizes(int(layout["stride"]), self.depth, self.num_owners, self.num_workers)
+        replica = layout.get("words") == "replica"
+        area = ControlBlocks.area_floats(world, self.num_workers) if replica else 0
+        sizes = region_sizes(int(layout["stride"]), self.depth, self.num_owners, self.num_workers, area)
         self.region = PeerRegion(self.rank, world, sizes[self.rank], self.device, self.cp0, name=self.ns + "/region",
                                  sizes=sizes)
         self.blocks = ControlBlocks(self.rank, world, self.cp0, name=self.ns + "/ctl", lanes=self.num_workers,
-                                    owner_rank=srv.ps_rank)
-        self.blocks.register_device(self.device, ranks=[self.rank])     # acknowledgements from a kernel behind the apply
+                                    owner_rank=srv.ps_rank, region=self.region if replica else None)
         self._owns_region = True
 
     def _configure(self, layout: dict):
@@ -377,8 +380,7 @@ class ParameterServerService:
                               n=self.n, slot_stride=S, var=self.var, m=self.slots.get("m", self.slots.get("momentum")),
                               v=self.slots.get("v"), inbox=self.region.local[3 * S:], step=self.step_t,
                               beta_powers=self.beta_powers, optimizer=self.opt,
-                              ctl_address=self.blocks.block_address(self.owner_index),
-                              ctl_dev_address=self.blocks.block_dev_address(self.owner_index))
+                              ctl_address=self.blocks.block_address(self.owner_index), blocks=self.blocks)
 
     def _quiesce(self):
         """Stop applying (what is launched completes): the shard is stable until ``_release``."""
@@ -464,8 +466,8 @@ class ParameterServerService:
                 if self._owns_region:
                     self.var = self.shard = None
                     self.slots = {}
+                    self.blocks.close()         # (replica mode: its views point into the region)
                     self.region.close()
-                    self.blocks.close()
         self.cp0.add(self.ns + "/stopped", 1)
         if self._owns_group and dist.is_initialized():
             try:
@@ -690,7 +692,8 @@ class AsyncPSStrategy:
         self._rejoined = False        # this process replaced a worker that died
         self._range_table = None      # peer_region.RangeTable of the owners' flat ranges (ps tasks on the region plane)
         self._link = None             # doorbell.PushLink: the native push of a GPU worker (stream, events, doorbells)
-        self._lanes_dev = None        # without a link: this worker's lanes as the GPU addresses them
+        self._direct_plans: Dict = {}  # batch size -> plan of the one-kernel step (train_step_direct), or None
+        self._flat_stale = False      # direct steps read the owners' memory: the local copy of the variables is behind
         self.blocks = None            # doorbell.ControlBlocks: the owners' words (region plane)
         self.depth = 1                # inbox slots per (owner, worker): gradients a worker may have outstanding
         self._pulled: List[int] = []  # owner versions seen at the last pull
@@ -815,11 +818,13 @@ class AsyncPSStrategy:
             S = self.slot_len = store.flat_len // self.num_owners
             self.depth = depth
             self.plane = "region"
-            self.region_floats = 3 * S + self.num_workers * self.depth * S
+            replica = ControlBlocks.replica_mode_available(dev)
+            self.region_floats = 3 * S + self.num_workers * self.depth * S + \
+                (ControlBlocks.area_floats(self.num_workers) if replica else 0)
             self.region = PeerRegion(self.worker_index, self.num_workers, self.region_floats, dev, self.cp0,
                                      name="co/region", timeout_s=self.timeout_s)
             self.blocks = ControlBlocks(self.worker_index, self.num_workers, self.cp0, name="co/ctl",
-                                        timeout_s=self.timeout_s)
+                                        timeout_s=self.timeout_s, region=self.region if replica else None)
             svc = ParameterServerService(server=srv, owner_index=self.worker_index,
                                          control=ControlClient(*srv.control_address(0), timeout_s=self.timeout_s),
                                          control0=ControlClient(*srv.control_address(0), timeout_s=self.timeout_s),
@@ -830,7 +835,7 @@ class AsyncPSStrategy:
             self._service = svc
             self._service_thread = threading.Thread(target=self._run_service, name="dtf-owner-%d" % self.worker_index,
                                                     daemon=True)
-            plane = {"plane": "region", "stride": S, "depth": self.depth}
+            plane = {"plane": "region", "stride": S, "depth": self.depth, "words": "replica" if replica else "shm"}
         else:
             # elastic workers: the second process to announce itself as worker i is its restarted successor, and
             # joins the running cluster instead of taking part in its start-up
@@ -861,14 +866,16 @@ class AsyncPSStrategy:
                                    "devices: set DTF_PS_DATA_PLANE=p2p" % (self.worker_index, dev.type, plane["device"]))
             self.plane = "region"
             self.slot_len, self.depth = int(plane["stride"]), int(plane["depth"])
-            sizes = region_sizes(self.slot_len, self.depth, self.num_owners, self.num_workers)
+            replica = plane.get("words") == "replica"
+            area = ControlBlocks.area_floats(srv.world_size, self.num_workers) if replica else 0
+            sizes = region_sizes(self.slot_len, self.depth, self.num_owners, self.num_workers, area)
             self.region_floats = sizes[srv.rank]
             self.region = PeerRegion(srv.rank, srv.world_size, self.region_floats, dev, self.cp0,
                                      name=self.ns + "/region", timeout_s=self.timeout_s, sizes=sizes,
                                      rejoin=self._rejoined)
             self.blocks = ControlBlocks(srv.rank, srv.world_size, self.cp0, name=self.ns + "/ctl",
                                         timeout_s=self.timeout_s, lanes=self.num_workers, owner_rank=srv.ps_rank,
-                                        rejoin=self._rejoined)
+                                        rejoin=self._rejoined, region=self.region if replica else None)
         elif not self.colocated:
             # data plane (after the layout is out: ps tasks join the process group once they have it)
             self.plane = "p2p"
@@ -884,21 +891,13 @@ class AsyncPSStrategy:
             self._sent_pulled = [[0] * self.num_owners for _ in range(self.depth)]
             self._acked = [0] * self.num_owners
             if dev.type == "cuda":
-                # the owners' words as this GPU addresses them (colocated: this rank's own block too, for its pump)
-                self.blocks.register_device(dev)
-                w = self.worker_index
-                lanes_dev = [self.blocks.lane_dev_address(j, w) for j in range(self.num_owners)]
                 S = self.slot_len
                 if self.region._kernels and (not self.colocated or (S % 4 == 0 and store.flat_len == S * self.num_owners)):
                     from .doorbell import PushLink
-                    self._link = PushLink(dev, self.region, None if self.colocated else self._owner_ranges_table(),
-                                          [self.blocks.lane_address(j, w) for j in range(self.num_owners)],
-                                          lanes_dev if all(lanes_dev) else None)
-                    if not self.colocated and not self._range_table.handle:
-                        self._link.close()
-                        self._link = None
+                    table = None if self.colocated else self._owner_ranges_table()
+                    if self.colocated or table.handle:
+                        self._link = PushLink(dev, self.region, table, self.blocks, self.worker_index, self.num_owners)
                 if self._link is None:
-                    self._lanes_dev = lanes_dev if all(lanes_dev) else None
                     self._comm_stream = torch.cuda.Stream(device=dev)
                     self._ev_grad, self._ev_copied = torch.cuda.Event(), torch.cuda.Event()
         if self._service_thread is not None:
@@ -961,7 +960,9 @@ class AsyncPSStrategy:
                                    "(ps tasks: %s)" % (dev.type, where))
             return {"plane": "p2p"}
         nmax = max([_ranges_numel(r) for r in self.ranges] + [1])
-        return {"plane": "region", "device": dev.type, "stride": (nmax + 63) // 64 * 64, "depth": depth}
+        from .doorbell import ControlBlocks
+        return {"plane": "region", "device": dev.type, "stride": (nmax + 63) // 64 * 64, "depth": depth,
+                "words": "replica" if ControlBlocks.replica_mode_available(dev, self.elastic) else "shm"}
 
     def close(self, grace_s: float = 20.0):
         """End this worker's owner thread: wait for the chief's shutdown request to reach it, and if none comes
@@ -979,11 +980,11 @@ class AsyncPSStrategy:
             if self._link is not None:
                 self._link.close()
                 self._link = None
+            if self.blocks is not None:
+                self.blocks.close()             # (replica mode: its views point into the region)
+                self.blocks = None
             self.region.close()
             self.region = None
-            if self.blocks is not None:
-                self.blocks.close()
-                self.blocks = None
 
     def _run_service(self):
         try:
@@ -1057,7 +1058,9 @@ class AsyncPSStrategy:
             upto = b.ack(j, w)
             for seq in range(self._acked[j] + 1, upto + 1):
                 slot = (seq - 1) % D
-                st = max(0, b.ack_version(j, w, slot) - 1 - self._sent_pulled[slot][j])
+                sent = self._sent_pulled[slot]
+                pulled = sent[j] if sent is not None else b.pull_version(j, w, slot)
+                st = max(0, b.ack_version(j, w, slot) - 1 - pulled)
                 self.staleness_hist[st] = self.staleness_hist.get(st, 0) + 1
             self._acked[j] = upto
 
@@ -1130,6 +1133,105 @@ class AsyncPSStrategy:
         if self.last_global_step:
             store.global_step.fill_(self.last_global_step)
 
+    # -- the whole step as ONE kernel: variables read from, gradients written to the ps tasks' memory
+    def _direct_plan(self, model, batch: int):
+        """ps tasks as owners, GPU, the reference network at a batch of at most 64: the fused gradient kernel can read
+        every variable straight from its owner's variable plane and write its gradient straight into this worker's
+        inbox slot there (peer-mapped memory), and ring the doorbells itself.  ``None`` when that does not apply
+        (``DTF_ASYNC_DIRECT=0`` switches it off)."""
+        if batch in self._direct_plans:
+            return self._direct_plans[batch]
+        import os
+        plan = None
+        store = model.store
+        b, w = self.blocks, self.worker_index
+        gp = model.fused_grad_plan(batch) if hasattr(model, "fused_grad_plan") else None
+        if (gp is not None and self.region is not None and not self.colocated and store.device.type == "cuda"
+                and self.num_owners <= 8 and os.environ.get("DTF_ASYNC_DIRECT", "1") != "0" and b is not None):
+            # with the control blocks registered the kernel rings the doorbells itself and reads the shared step from
+            # owner 0's word; otherwise the doorbells are rung behind it and the step comes from the worker's mirror
+            in_kernel = b.replicas is not None
+            where = []                       # per variable: (owner, position in the owner's packed shard)
+            eff_vars = [(off, n) for off, n in zip(gp["offsets"], self._plan_numels(gp))]
+            for off, n in eff_vars:
+                hit = None
+                for j in range(self.num_owners):
+                    pos = 0
+                    for lo, hi in self.ranges[j]:
+                        if lo <= off and off + n <= hi:
+                            hit = (j, pos + off - lo)
+                        pos += hi - lo
+                where.append(hit)
+            if all(h is not None for h in where):
+                S, D = self.slot_len, self.depth
+                var_ptrs = [self.region.peer_address(self.owner_rank(j), pos) for j, pos in where]
+                grad_ptrs = [[self.region.peer_address(self.owner_rank(j), 3 * S + (w * D + slot) * S + pos) for j, pos in where]
+                             for slot in range(D)]
+                plan = dict(gp=gp, var_ptrs=var_ptrs, grad_ptrs=grad_ptrs, in_kernel=in_kernel,
+                            step=b.global_step_address() if in_kernel else store.global_step.data_ptr())
+        self._direct_plans[batch] = plan
+        return plan
+
+    @staticmethod
+    def _plan_numels(gp):
+        d0, d1, d2, d3 = gp["dims"]
+        return [d0 * d1, d1, d1 * d2, d2, d2 * d3, d3]
+
+    def train_step_direct(self, model, x, y) -> bool:
+        """One training step as one kernel launch (see ``_direct_plan``); False when the step has to take the general
+        path (``compute_gradients`` + ``apply_gradients``)."""
+        if not (x.is_cuda and x.dim() == 2 and y.dim() == 2 and y.dtype == torch.float32 and x.shape[0] <= 64):
+            return False
+        plan = self._direct_plan(model, int(x.shape[0]))
+        if plan is None:
+            return False
+        from ..ops import functional as F
+        t_begin = time.perf_counter()
+        w0 = self.wait_seconds
+        D = self.depth
+        t = self.clock
+        slot = t % D
+        if t >= D:
+            self.wait_seconds += self._spin(lambda: self._min_ack() >= t + 1 - D, "a free inbox slot")
+        self._account_acks()
+        gp = plan["gp"]
+        if plan["in_kernel"]:
+            self._sent_pulled[slot] = None      # the kernel reads the owners' versions itself: taken from the lane words
+        else:
+            for j in range(self.num_owners):
+                self._pulled[j] = self.blocks.version(j)
+            self._sent_pulled[slot] = list(self._pulled)
+            if self.last_global_step:
+                model.store.global_step.fill_(self.last_global_step)
+        F.mlp3_fused_grad_direct(x.contiguous(), y.contiguous(), plan["var_ptrs"], plan["grad_ptrs"][slot], gp["dims"], True,
+                                 model._extra_categorical, gp["l1"].fused_keep, gp["l2"].fused_keep, gp["l1"].seed,
+                                 gp["l2"].seed, plan["step"], model.stats, self.blocks if plan["in_kernel"] else None,
+                                 self.worker_index, self.num_owners, slot, t + 1, t + 1)
+        if not plan["in_kernel"]:
+            from .doorbell import ring
+            ring(torch.cuda.current_stream(model.store.device).cuda_stream, True, self.blocks, self.worker_index,
+                 self.num_owners, self._pulled, slot, t + 1, t + 1)
+        self.clock = t + 1
+        lag = D - 1
+        if self._min_ack() < self.clock - lag:
+            self.wait_seconds += self._spin(lambda: self._min_ack() >= self.clock - lag, "the owners' acknowledgement")
+        if self.max_staleness is not None:
+            s = self.max_staleness
+            if self.clock - self.min_clock() > s:
+                self.wait_seconds += self._spin(lambda: self.clock - self.min_clock() <= s,
+                                                "the slowest worker (staleness bound)")
+        self.last_global_step = max(self.last_global_step, self.blocks.global_step())
+        self._flat_stale = True
+        self.comm_seconds += time.perf_counter() - t_begin - (self.wait_seconds - w0)
+        return True
+
+    def ensure_fresh(self, model):
+        """Before anything reads the worker's own copy of the variables (evaluation, prediction): direct steps never
+        refresh it."""
+        if self._flat_stale:
+            self.pull(model)
+            model.store.global_step.fill_(self.last_global_step)
+
     def _push_stepwise(self, store, on_gpu: bool, inbox: int, slot: int, seq: int):
         """The push without the native link (CPUs; GPUs with DTF_PEER_KERNELS=0): the same steps, one call each."""
         from .doorbell import ring
@@ -1149,8 +1251,7 @@ class AsyncPSStrategy:
                 self.region.move_ranges(self._owner_ranges_table(), False, inbox, store.flat_grad)
             if on_gpu:
                 self._ev_copied.record(self._comm_stream)
-            ring(self._comm_stream.cuda_stream if on_gpu else 0, on_gpu,
-                 [self.blocks.lane_address(j, w) for j in range(W)], self._pulled, slot, seq, seq, self._lanes_dev)
+            ring(self._comm_stream.cuda_stream if on_gpu else 0, on_gpu, self.blocks, w, W, self._pulled, slot, seq, seq)
         if on_gpu:
             cur.wait_event(self._ev_copied)              # the next backward pass may overwrite the gradient buffer
 
@@ -1190,6 +1291,7 @@ class AsyncPSStrategy:
         if self.region is not None:
             self._drain()
             self._region_pull(store)
+            self._flat_stale = False
             return
         self._post("pull")
         recvs, bufs = self._receive_params(store)

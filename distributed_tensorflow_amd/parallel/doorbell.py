@@ -1,14 +1,14 @@
 """Doorbell words and the native owner pump of the asynchronous parameter-server mode.
 
-Every owner has one *control block* in host memory shared by all processes of the node (POSIX shared memory): a
-header (``version``, ``global_step``) and one 128-byte *lane* per worker with the worker's doorbell / clock and the
-owner's acknowledgement.  Workers and owners exchange gradients and parameters through peer-mapped device memory
-(:mod:`.peer_region`); these words are all that tells the other side that data is complete, so a training step makes
-no control-plane round trip and never synchronises a stream on the host.  On GPUs every process registers the blocks
-with the HIP runtime (``ControlBlocks.register_device``) and the words are written by one-workgroup kernels queued
-behind the copies / the apply kernel (system-scope release stores into coherent host memory); a GPU worker's whole
-push is one native call (:class:`PushLink`).  The layout is the one of
+Every owner has one *control block*: a header (``version``, ``global_step``) and one 128-byte *lane* per worker with the
+worker's doorbell / clock and the owner's acknowledgement.  Workers and owners exchange gradients and parameters through
+peer-mapped device memory (:mod:`.peer_region`); these words are all that tells the other side that data is complete, so
+a training step makes no control-plane round trip and never synchronises a stream on the host.  The layout is the one of
 ``csrc/kernels/owner_pump.hip`` (``Ctl`` / ``Lane``), which also holds the owner's service thread.
+
+On GPUs the blocks live as replicas in every rank's own device memory and are written by kernels in stream order
+(:class:`ControlBlocks`, replica mode); a GPU worker's whole push is one native call (:class:`PushLink`).  On CPUs - and
+where a GPU's memory is not addressable by its host - they are POSIX shared memory written by host code.
 
 The reference's counterpart is TF's gRPC worker service inside ``server.join()``
 (/root/reference/example.py:128-131): it executes ``ApplyAdam`` for every gradient that arrives.
@@ -52,13 +52,13 @@ def _k():
         nv.declare(lib, "dtf_pump_stream", [p], p)
         nv.declare(lib, "dtf_pump_histogram", [p, p], None)
         nv.declare(lib, "dtf_pump_stop", [p])
-        nv.declare(lib, "dtf_doorbell_ring", [p, C.c_int, p, p, p, C.c_int, C.c_int, ull, ull])
-        nv.declare(lib, "dtf_host_register", [p, ll, p])
-        nv.declare(lib, "dtf_host_unregister", [p])
+        nv.declare(lib, "dtf_doorbell_ring", [p, C.c_int, p, p, C.c_int, p, p, C.c_int, C.c_int, ull, ull])
+        nv.declare(lib, "dtf_words_broadcast", [p, C.c_int, ll, ull, p])
+        nv.declare(lib, "dtf_device_large_bar", [])
         nv.declare(lib, "dtf_link_create", [], p)
         nv.declare(lib, "dtf_link_destroy", [p], None)
         nv.declare(lib, "dtf_link_stream", [p], p)
-        nv.declare(lib, "dtf_link_push", [p, p, p, p, p, ll, ll, ll, p, p, p, C.c_int, C.c_int, ull, ull])
+        nv.declare(lib, "dtf_link_push", [p, p, p, p, p, ll, ll, ll, p, p, C.c_int, p, p, C.c_int, C.c_int, ull, ull])
         assert lib.dtf_pump_lane_bytes() == _LANE_WORDS * 8
         _lib = lib
     return _lib
@@ -71,7 +71,8 @@ class _PumpConfig(C.Structure):
                 ("var", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("inbox", C.c_void_p),
                 ("step", C.c_void_p), ("beta_powers", C.c_void_p), ("ticket", C.c_void_p),
                 ("lr", C.c_float), ("b1", C.c_float), ("b2", C.c_float), ("eps", C.c_float), ("momentum", C.c_float),
-                ("pad2", C.c_int), ("ctl", C.c_void_p), ("ctl_dev", C.c_void_p)]
+                ("pad2", C.c_int), ("ctl", C.c_void_p), ("rep_base", C.c_void_p * 64), ("rep_world", C.c_int),
+                ("pad3", C.c_int), ("block_word", C.c_longlong)]
 
 
 class ControlBlocks:
@@ -79,21 +80,66 @@ class ControlBlocks:
     ranks sharing ``name`` on the control plane ``cp``: rank ``r`` creates one block with ``lanes`` lanes (default
     ``world``: every rank is a worker and an owner).  ``owner_rank(j)`` is the rank whose block owner ``j`` uses
     (default ``j``); with ps tasks the owners are the first ranks and the lanes count the workers only.  All methods
-    take owner and worker *indices*."""
+    take owner and worker *indices*.
+
+    Two homes for the words:
+
+    * POSIX shared memory, one segment per block, written by host code (CPUs; GPUs fall back to it, with the writes in
+      stream host functions);
+    * *replica mode* (``region`` given, a GPU whose memory the CPU can address, ``DTF_DOORBELL_KERNELS`` not 0): every
+      rank holds a replica of ALL blocks in the last ``area_floats(world, lanes)`` floats of its peer region - its own
+      device memory, which its CPU reads through the large BAR - and every update is stored into all replicas by a
+      kernel (``ring`` / the pump's acknowledgement / ``_broadcast``), in stream order behind the data it announces.
+      A process cannot be re-admitted in this mode (nobody would map its new region), so elastic clusters use the
+      shared-memory home."""
+
+    @staticmethod
+    def area_floats(world: int, lanes: Optional[int] = None) -> int:
+        """Floats a rank's region must reserve at its end for replica mode."""
+        return 2 * int(world) * (_HDR_WORDS + _LANE_WORDS * int(world if lanes is None else lanes))
+
+    @staticmethod
+    def replica_mode_available(device, elastic: bool = False) -> bool:
+        import os
+        if torch.device(device).type != "cuda" or elastic or os.environ.get("DTF_DOORBELL_KERNELS", "1") == "0":
+            return False
+        with torch.cuda.device(device):
+            return bool(_k().dtf_device_large_bar())
 
     def __init__(self, rank: int, world: int, cp, name: str = "co/ctl", timeout_s: float = 300.0,
-                 lanes: Optional[int] = None, owner_rank=None, rejoin: bool = False):
+                 lanes: Optional[int] = None, owner_rank=None, rejoin: bool = False, region=None):
         from multiprocessing import resource_tracker, shared_memory
         self.rank, self.world = int(rank), int(world)
         self.lanes = self.world if lanes is None else int(lanes)
         self._blk = owner_rank if owner_rank is not None else (lambda j: j)
-        nbytes = (_HDR_WORDS + _LANE_WORDS * self.lanes) * 8
+        self._block_words = _HDR_WORDS + _LANE_WORDS * self.lanes
+        nbytes = self._block_words * 8
+        self._nbytes = nbytes
+        self._shms: List = []
+        self._mine = None
+        self.replicas: Optional[List[int]] = None       # replica mode: every rank's control area as this GPU addresses it
+        self._rep_array = None
+        if region is not None:
+            # replica mode: the areas were zeroed with the regions, and every region is mapped when its constructor returns
+            area = self.area_floats(self.world, self.lanes)
+            self.replicas = [region.peer_address(r, region.sizes[r] - area) for r in range(self.world)]
+            if not all(self.replicas):
+                raise RuntimeError("a peer region is not mapped")
+            self._rep_array = (C.c_void_p * self.world)(*self.replicas)
+            self._device = region.device
+            local = self.replicas[self.rank]
+            self._base = [local + k * nbytes for k in range(self.world)]
+            self._views = [(C.c_uint64 * self._block_words).from_address(b) for b in self._base]
+            self.words = [np.ctypeslib.as_array(v) for v in self._views]
+            if not rejoin:
+                cp.barrier("%s/mapped" % name, self.world, timeout_s=timeout_s)
+            return
         seg = "dtfc_%s_%d" % (uuid.uuid4().hex[:12], self.rank)
         _CREATED_HERE.add(seg)
         self._mine = shared_memory.SharedMemory(name=seg, create=True, size=nbytes)
         self._mine.buf[:nbytes] = bytes(nbytes)
         cp.set("%s/handle/%d" % (name, self.rank), seg.encode())
-        self._shms: List = [None] * self.world
+        self._shms = [None] * self.world
         self._shms[self.rank] = self._mine
         for r in range(self.world):
             if r == self.rank:
@@ -108,42 +154,26 @@ class ControlBlocks:
             self._shms[r] = shm
         self.words = [np.frombuffer(s.buf, dtype=np.uint64, count=nbytes // 8) for s in self._shms]
         self._base = [C.addressof(C.c_char.from_buffer(s.buf)) for s in self._shms]
-        self._nbytes = nbytes
-        self._dev_base: List[Optional[int]] = [None] * self.world       # the blocks as this process's GPU addresses them
-        self._registered: List[int] = []
         if not rejoin:      # a restarted process maps the blocks of ranks that have been running for a while
             cp.barrier("%s/mapped" % name, self.world, timeout_s=timeout_s)
 
-    # ---- GPU access to the words
-    def register_device(self, device, ranks=None) -> bool:
-        """Make the blocks of ``ranks`` (default: all) addressable by this process's GPU, so that doorbells and
-        acknowledgements are written by kernels in stream order instead of host callbacks.  ``DTF_DOORBELL_KERNELS=0``
-        (or a runtime that refuses to register shared memory) keeps the host functions; returns whether kernels are on."""
-        import os
-        if torch.device(device).type != "cuda" or os.environ.get("DTF_DOORBELL_KERNELS", "1") == "0":
-            return False
-        lib = _k()
-        with torch.cuda.device(device):
-            for r in (range(self.world) if ranks is None else ranks):
-                if self._dev_base[r] is not None:
-                    continue
-                out = C.c_void_p()
-                if lib.dtf_host_register(C.c_void_p(self._base[r]), self._nbytes, C.byref(out)) or not out.value:
-                    for b in self._registered:
-                        lib.dtf_host_unregister(C.c_void_p(b))
-                    self._registered = []
-                    self._dev_base = [None] * self.world
-                    return False
-                self._registered.append(self._base[r])
-                self._dev_base[r] = out.value
-        return True
+    # ---- replica mode: positions inside a control area, in 64-bit words
+    def block_word(self, owner: int) -> int:
+        return self._blk(owner) * self._block_words
 
-    def block_dev_address(self, owner: int) -> Optional[int]:
-        return self._dev_base[self._blk(owner)]
+    def lane_word(self, owner: int, worker: int) -> int:
+        return self.block_word(owner) + _HDR_WORDS + _LANE_WORDS * worker
 
-    def lane_dev_address(self, owner: int, worker: int) -> Optional[int]:
-        b = self._dev_base[self._blk(owner)]
-        return None if b is None else b + (_HDR_WORDS + _LANE_WORDS * worker) * 8
+    def global_step_address(self) -> Optional[int]:
+        """Replica mode: the shared global step (owner 0's word) in this rank's own device memory."""
+        return None if self.replicas is None else self._base[self._blk(0)] + _GSTEP * 8
+
+    def _broadcast(self, word: int, value: int):
+        """Replica mode: one word, the same value into every replica (a kernel; returns when it has completed)."""
+        with torch.cuda.device(self._device):
+            rc = _k().dtf_words_broadcast(self._rep_array, self.world, int(word), int(value) % (1 << 64), None)
+        if rc:
+            raise RuntimeError("control word broadcast failed (%d)" % rc)
 
     # ---- addresses for the native side
     def block_address(self, owner: int) -> int:
@@ -168,6 +198,9 @@ class ControlBlocks:
     def ack(self, owner: int, worker: int) -> int:
         return int(self._w(owner)[self._lane(owner, worker) + _ACK])
 
+    def pull_version(self, owner: int, worker: int, slot: int) -> int:
+        return int(self._w(owner)[self._lane(owner, worker) + _PULLV + slot])
+
     def ack_version(self, owner: int, worker: int, slot: int) -> int:
         return int(self._w(owner)[self._lane(owner, worker) + _ACKV + slot])
 
@@ -178,6 +211,9 @@ class ControlBlocks:
         return int(self._w(0)[self._lane(0, worker) + _CLOCK])
 
     def set_clock(self, worker: int, value: int):
+        if self.replicas is not None:
+            self._broadcast(self.lane_word(0, worker) + _CLOCK, value)
+            return
         self._w(0)[self._lane(0, worker) + _CLOCK] = np.uint64(value)
 
     def min_clock(self, skip=()) -> int:
@@ -189,6 +225,10 @@ class ControlBlocks:
     def set_lane(self, owner: int, worker: int, seq: int):
         """Owner side, pump paused: a restarted worker continues its lane at gradient number ``seq`` - whatever its
         predecessor rang but never completed is dropped."""
+        if self.replicas is not None:
+            self._broadcast(self.lane_word(owner, worker) + _DOOR, seq)
+            self._broadcast(self.lane_word(owner, worker) + _ACK, seq)
+            return
         w = self._w(owner)
         w[self._lane(owner, worker) + _DOOR] = np.uint64(seq)
         w[self._lane(owner, worker) + _ACK] = np.uint64(seq)
@@ -198,17 +238,18 @@ class ControlBlocks:
         and ``version`` stay monotonic (workers keep counting), only the step's base moves.  Pump paused."""
         w = self._w(owner)
         version = int(w[_VERSION])
-        w[_GSBASE] = np.uint64((int(global_step) - version) % (1 << 64))
+        w[_GSBASE] = np.uint64((int(global_step) - version) % (1 << 64))       # read by this owner's pump only
+        if self.replicas is not None:
+            self._broadcast(self.block_word(owner) + _GSTEP, int(global_step))
+            return
         w[_GSTEP] = np.uint64(int(global_step))
 
     def close(self):
-        if self._registered:
-            lib = _k()
-            for b in self._registered:
-                lib.dtf_host_unregister(C.c_void_p(b))
-            self._registered = []
         self.words = []
         self._base = []
+        self._views = []
+        if self._mine is None:
+            return              # replica mode: the memory belongs to the peer region
         for i, s in enumerate(self._shms):
             if s is None:
                 continue
@@ -223,36 +264,45 @@ class ControlBlocks:
         self._shms = []
 
 
-def ring(stream_ptr: int, on_gpu: bool, lanes: List[int], pulled: List[int], slot: int, seq: int, clock: int,
-         lanes_dev: Optional[List[int]] = None):
-    """After everything queued on the stream so far: publish gradient number ``seq`` of this worker (slot ``slot`` of
-    the inboxes) to the owners whose lanes are given; ``lanes[0]`` must be the lane in owner 0's block.  ``lanes_dev``:
-    the lanes as the GPU addresses them (``ControlBlocks.register_device``): a kernel writes the words."""
-    n = len(lanes)
-    la = (C.c_void_p * n)(*lanes)
-    ld = (C.c_void_p * n)(*lanes_dev) if lanes_dev else None
+def ring(stream_ptr: int, on_gpu: bool, blocks: "ControlBlocks", worker: int, owners: int, pulled: List[int], slot: int,
+         seq: int, clock: int):
+    """After everything queued on the stream so far: publish gradient number ``seq`` of worker ``worker`` (slot ``slot``
+    of the inboxes) to owners ``0 .. owners-1``.  Replica mode: a kernel on the stream stores the words into every
+    replica; otherwise host code writes the shared-memory lanes (from a stream host function on a GPU)."""
+    n = int(owners)
     pv = (C.c_ulonglong * n)(*pulled)
-    rc = _k().dtf_doorbell_ring(C.c_void_p(stream_ptr or 0), 1 if on_gpu else 0, la, ld, pv, n, int(slot), int(seq), int(clock))
+    if blocks.replicas is not None:
+        lw = (C.c_longlong * n)(*[blocks.lane_word(j, worker) for j in range(n)])
+        rc = _k().dtf_doorbell_ring(C.c_void_p(stream_ptr or 0), 1, None, blocks._rep_array, blocks.world, lw, pv, n,
+                                    int(slot), int(seq), int(clock))
+    else:
+        la = (C.c_void_p * n)(*[blocks.lane_address(j, worker) for j in range(n)])
+        rc = _k().dtf_doorbell_ring(C.c_void_p(stream_ptr or 0), 1 if on_gpu else 0, la, None, 0, None, pv, n, int(slot),
+                                    int(seq), int(clock))
     if rc:
         raise RuntimeError("doorbell failed (%d)" % rc)
 
 
 class PushLink:
     """A GPU worker's native link to its owners (``dtf_link_*`` in ``csrc/kernels/owner_pump.hip``): the communication
-    stream and events of the push, the lane addresses, and one call per step that queues everything - wait for the
-    backward pass, move the gradient into the owners' inboxes, ring the doorbells, release the gradient buffer."""
+    stream and events of the push, and one call per step that queues everything - wait for the backward pass, move the
+    gradient into the owners' inboxes, ring the doorbells, release the gradient buffer."""
 
-    def __init__(self, device, region, table, lanes: List[int], lanes_dev: Optional[List[int]]):
+    def __init__(self, device, region, table, blocks: "ControlBlocks", worker: int, owners: int):
         self.device = torch.device(device)
         lib = _k()
         with torch.cuda.device(self.device):
             self._h = lib.dtf_link_create()
         if not self._h:
             raise RuntimeError("cannot create the push link")
-        self._region, self._table = region, table
-        n = self.n = len(lanes)
-        self._lanes = (C.c_void_p * n)(*lanes)
-        self._lanes_dev = (C.c_void_p * n)(*lanes_dev) if lanes_dev else None
+        self._region, self._table, self._blocks = region, table, blocks
+        n = self.n = int(owners)
+        if blocks.replicas is not None:
+            self._lanes = None
+            self._lane_words = (C.c_longlong * n)(*[blocks.lane_word(j, worker) for j in range(n)])
+        else:
+            self._lanes = (C.c_void_p * n)(*[blocks.lane_address(j, worker) for j in range(n)])
+            self._lane_words = None
         self._pulled = (C.c_ulonglong * n)()
 
     def stream_ptr(self) -> int:
@@ -262,10 +312,11 @@ class PushLink:
              seq: int, clock: int):
         for i, v in enumerate(pulled):
             self._pulled[i] = v
+        b = self._blocks
         rc = _k().dtf_link_push(self._h, self._region._h, self._table.handle if self._table is not None else None,
                                 C.c_void_p(cur_stream_ptr or 0), grad.data_ptr(), grad.numel() * 4, int(remote_base) * 4,
-                                int(shard_floats) * 4, self._lanes, self._lanes_dev, self._pulled, self.n, int(slot), int(seq),
-                                int(clock))
+                                int(shard_floats) * 4, self._lanes, b._rep_array if b.replicas is not None else None,
+                                b.world, self._lane_words, self._pulled, self.n, int(slot), int(seq), int(clock))
         if rc:
             raise RuntimeError("push to the owners failed (%d)" % rc)
 
@@ -280,7 +331,7 @@ class OwnerPump:
     """The owner's native service thread: applies arriving gradient shards to ``var`` / slots on its own stream."""
 
     def __init__(self, *, device, owner: int, workers: int, depth: int, n: int, slot_stride: int, var, m, v, inbox,
-                 step, beta_powers, optimizer, ctl_address: int, ctl_dev_address: Optional[int] = None):
+                 step, beta_powers, optimizer, ctl_address: int, blocks: Optional["ControlBlocks"] = None):
         lib = _k()
         assert lib.dtf_pump_config_bytes() == C.sizeof(_PumpConfig), "owner_pump.hip and doorbell.py disagree"
         self.device = torch.device(device)
@@ -300,7 +351,12 @@ class OwnerPump:
         else:
             cfg.lr, cfg.b1, cfg.b2, cfg.eps, cfg.momentum = optimizer.lr, 0.0, 0.0, 0.0, optimizer.momentum
         cfg.ctl = ctl_address
-        cfg.ctl_dev = ctl_dev_address if on_gpu else None     # acknowledgements written by a kernel behind the apply
+        if on_gpu and blocks is not None and blocks.replicas is not None:
+            # replica mode: acknowledgements stored into every rank's replica by a kernel behind the apply
+            for r, a in enumerate(blocks.replicas):
+                cfg.rep_base[r] = a
+            cfg.rep_world = blocks.world
+            cfg.block_word = blocks.block_word(owner)
         if on_gpu:
             with torch.cuda.device(self.device):
                 self._h = lib.dtf_pump_start(C.byref(cfg))

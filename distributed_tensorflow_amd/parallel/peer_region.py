@@ -39,6 +39,7 @@ def _k():
         nv.declare(lib, "dtf_mbox_handle_bytes", [])
         nv.declare(lib, "dtf_mbox_bytes", [p], ll)
         nv.declare(lib, "dtf_mbox_local_ptr", [p], p)
+        nv.declare(lib, "dtf_mbox_peer_ptr", [p, C.c_int], p)
         nv.declare(lib, "dtf_mbox_local_handle", [p, p])
         nv.declare(lib, "dtf_mbox_open_peer", [p, C.c_int, p])
         nv.declare(lib, "dtf_mbox_set_peer_bytes", [p, C.c_int, ll])
@@ -229,6 +230,15 @@ class PeerRegion:
             return
         for j in range(self.world):
             self.put(j, dst_off, src[j * n:(j + 1) * n])
+
+    def peer_address(self, peer: int, off: int = 0) -> Optional[int]:
+        """Device address of float ``off`` of rank ``peer``'s region as this process's kernels see it (GPU only)."""
+        if self._h is None:
+            return None
+        if not 0 <= off <= self.sizes[peer]:
+            raise ValueError("offset %d outside rank %d's region" % (off, peer))
+        base = _k().dtf_mbox_peer_ptr(self._h, int(peer))
+        return None if not base else int(base) + int(off) * 4
 
     def make_ranges(self, ranges) -> RangeTable:
         """Prepare ``ranges`` = ``[(peer, remote_off, local_off, n), ...]`` (floats) for ``move_ranges``."""

@@ -10,6 +10,8 @@ import sys
 
 import pytest
 
+from distributed_tensorflow_amd.saver import BundleReader
+
 from .test_example_cluster import _env, _ports
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -34,12 +36,23 @@ if job == "ps":
     sys.exit(0)
 strat = AsyncPSStrategy(srv, max_staleness=2)
 assert not strat.colocated and strat.num_owners == len(ps_hosts)
-m = Sequential([Dense(32, input_dim=784, activation="relu"), Dropout(0.3), Dense(24, activation="relu"),
-                Dense(10, activation="softmax")])
-m.compile(loss="sparse_categorical_crossentropy", optimizer="adam", metrics=["accuracy"], strategy=strat, device=device,
-          seed=10 + index)
+reference_net = os.environ.get("DTF_TEST_MODEL") == "xor"
+if reference_net:
+    # the reference network at its own batch size: on a GPU a worker's whole step is one kernel that reads the ps
+    # tasks' memory and writes into their inboxes
+    from distributed_tensorflow_amd.data import get_data
+    from distributed_tensorflow_amd.models import xor_mlp
+    m = xor_mlp()
+    m.compile(loss="mean_squared_error", optimizer="adam", metrics=["binary_rounded_accuracy"], strategy=strat,
+              device=device, seed=10 + index)
+    x, y = get_data(64 * steps, val_set_size=0, seed=index)[:2]
+else:
+    m = Sequential([Dense(32, input_dim=784, activation="relu"), Dropout(0.3), Dense(24, activation="relu"),
+                    Dense(10, activation="softmax")])
+    m.compile(loss="sparse_categorical_crossentropy", optimizer="adam", metrics=["accuracy"], strategy=strat, device=device,
+              seed=10 + index)
+    x, y = mnist_like(64 * steps, seed=index)
 assert not m.store.slots                      # nobody but the owners holds optimizer state
-x, y = mnist_like(64 * steps, seed=index)
 x, y = x.to(device), y.to(device)
 losses = []
 calls0 = strat.control_calls()
@@ -63,6 +76,8 @@ if srv.is_chief:
 print("RESULT " + json.dumps({"index": index, "global_step": gs, "sum": float(m.store.flat.double().sum()),
                               "loss0": losses[0], "loss_last": losses[-1], "plane": strat.plane, "calls": calls,
                               "ranges": [len(r) for r in strat.ranges], "process_group": dist.is_initialized(),
+                              "direct": any(p is not None for p in strat._direct_plans.values()),
+                              "replica_words": strat.blocks is not None and strat.blocks.replicas is not None,
                               "stale_max": max(strat.staleness_hist), "owner_stats": stats,
                               "flat": m.store.flat.tolist() if srv.is_chief else None,
                               "names": [[v.name, v.offset, v.numel] for v in m.store.trainable]}))
@@ -82,11 +97,29 @@ def test_two_ps_tasks_two_workers_share_the_gpu(tmp_path):
     for k in ("JOB_NAME", "TASK_INDEX", "PS_HOSTS", "WORKER_HOSTS"):
         env.pop(k, None)
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
-    _run(tmp_path, "region", "cuda:0", env)
+    results = _run(tmp_path, "region", "cuda:0", env)
+    assert not any(r["direct"] for r in results)          # not the reference network: push / pull through the link
 
 
-def _run(tmp_path, plane, device, base_env):
-    n_ps, n_w, steps = 2, 2, 12
+@pytest.mark.gpu
+def test_reference_network_one_kernel_per_worker_step(tmp_path):
+    """The reference network at batch 64 with its variables on two ps tasks, everything on one MI355X: a worker's step is
+    ONE kernel - variables read from the ps tasks' variable planes, gradients written into the worker's inbox slots there,
+    doorbells rung by the same launch - and training behaves as on the general path (shared step, versions, equal
+    variables everywhere after the final pull, owner-written checkpoint, falling loss)."""
+    env = dict(os.environ)
+    for k in ("JOB_NAME", "TASK_INDEX", "PS_HOSTS", "WORKER_HOSTS"):
+        env.pop(k, None)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    env["DTF_TEST_MODEL"] = "xor"
+    results = _run(tmp_path, "region", "cuda:0", env, steps=60)
+    assert all(r["direct"] for r in results)
+    # the control words live as replicas in every rank's own device memory: the kernel rang the doorbells itself
+    assert all(r["replica_words"] for r in results)
+
+
+def _run(tmp_path, plane, device, base_env, steps=12):
+    n_ps, n_w = 2, 2
     ports = _ports(n_ps + n_w + 1)
     ps_hosts = ",".join("127.0.0.1:%d" % p for p in ports[:n_ps])
     w_hosts = ",".join("127.0.0.1:%d" % p for p in ports[n_ps:n_ps + n_w])
@@ -127,7 +160,6 @@ def _run(tmp_path, plane, device, base_env):
         assert all(r["calls"] >= 2 * steps and r["process_group"] for r in results)
     # the owners wrote the checkpoint (one data shard each); it holds what the chief pulled afterwards
     import torch
-    from distributed_tensorflow_amd.saver import BundleReader
     flat = torch.tensor(results[0]["flat"])
     with BundleReader(prefix) as r:
         assert r.num_shards == n_ps
@@ -135,3 +167,4 @@ def _run(tmp_path, plane, device, base_env):
             assert torch.equal(r.get_tensor(name).reshape(-1), flat[off:off + numel]), name
             assert r.has_tensor(name + "/Adam") and r.has_tensor(name + "/Adam_1")
         assert int(r.get_tensor("global_step").item()) == n_w * steps
+    return results
