@@ -670,6 +670,9 @@ def run_rank(args) -> None:
                        **({"device": "cpu (plumbing rehearsal, not a benchmark)"} if not on_gpu else {}),
                        **({"max_staleness": args.max_staleness, "staleness_histogram_rank0": staleness,
                            "inbox_depth": strategy.depth, "wait_seconds_rank0": strategy.wait_seconds,
+                           "control_words": ("replicas in device memory, written by kernels"
+                                             if getattr(strategy.blocks, "replicas", None) is not None
+                                             else "shared memory, written by host code"),
                            "host_comm_seconds_rank0": strategy.comm_seconds}
                           if staleness is not None else {})},
         }
