@@ -18,8 +18,8 @@
 //
 // Where the words live.  On GPUs whose memory the CPU can address (large BAR: every MI355X) each rank keeps a replica
 // of all control blocks at the end of its peer region, in ITS OWN device memory: a CPU reads words only from the
-// replica of its own process (the CPU cannot address memory mapped from another process's hipIpc handle, and the
-// runtime does not register POSIX shared memory for GPU access), and every word is written by a one-workgroup kernel
+// replica of its own process (the CPU cannot address memory mapped from another process's hipIpc handle, and host
+// memory cannot be registered for GPU access everywhere), and every word is written by a one-workgroup kernel
 // that stores it into all replicas through the peer mappings - queued right behind the copies / the apply kernel on
 // the same stream (stream order: the data is complete when the word changes; system-scope release stores).  No host
 // callback sits between a gradient's arrival and its apply, or between the apply and its acknowledgement.
