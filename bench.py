@@ -88,7 +88,7 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
-DEFAULT_BATCH = {"mnist_mlp": 262144, "xor_mlp": 32768, "mnist_cnn": 4096, "wide_mlp": 8192}
+DEFAULT_BATCH = {"mnist_mlp": 262144, "xor_mlp": 32768, "mnist_cnn": 16384, "wide_mlp": 8192}
 
 
 # ----------------------------------------------------------------------------------------------- launcher
