@@ -1148,8 +1148,8 @@ class AsyncPSStrategy:
         gp = model.fused_grad_plan(batch) if hasattr(model, "fused_grad_plan") else None
         if (gp is not None and self.region is not None and not self.colocated and store.device.type == "cuda"
                 and self.num_owners <= 8 and os.environ.get("DTF_ASYNC_DIRECT", "1") != "0" and b is not None):
-            # with the control blocks registered the kernel rings the doorbells itself and reads the shared step from
-            # owner 0's word; otherwise the doorbells are rung behind it and the step comes from the worker's mirror
+            # control blocks in replica mode: the kernel rings the doorbells itself and reads the shared step from owner
+            # 0's word; in shared memory: the doorbells are rung behind it and the step comes from the worker's mirror
             in_kernel = b.replicas is not None
             where = []                       # per variable: (owner, position in the owner's packed shard)
             eff_vars = [(off, n) for off, n in zip(gp["offsets"], self._plan_numels(gp))]
