@@ -114,8 +114,10 @@ def test_reference_network_one_kernel_per_worker_step(tmp_path):
     env["DTF_TEST_MODEL"] = "xor"
     results = _run(tmp_path, "region", "cuda:0", env, steps=60)
     assert all(r["direct"] for r in results)
-    # the control words live as replicas in every rank's own device memory: the kernel rang the doorbells itself
-    assert all(r["replica_words"] for r in results)
+    # where the CPU can address the GPU's memory the control words live as replicas in every rank's own device memory
+    # and the kernel rang the doorbells itself
+    from distributed_tensorflow_amd.parallel.doorbell import ControlBlocks
+    assert all(r["replica_words"] == ControlBlocks.replica_mode_available("cuda:0") for r in results)
 
 
 def _run(tmp_path, plane, device, base_env, steps=12):
