@@ -1,6 +1,7 @@
 """The asynchronous parameter-server data plane on a GPU: workers with colocated owners exchange gradient and
-variable shards through hipIpc-mapped peer regions, and doorbell words in shared host memory (written by stream host
-functions) replace every per-step message.  2 and 4 self-launched ranks time-share the one GPU of the test box; on an
+variable shards through hipIpc-mapped peer regions, and doorbell words replace every per-step message - replicas in
+every rank's device memory written by kernels where the CPU can address that memory, else (and in the last case here)
+shared host memory written by stream host functions.  2 and 4 self-launched ranks time-share the one GPU of the test box; on an
 8-GPU node the same code runs with one rank per GPU over xGMI.
 
 Checked: training converges, a step makes no control-plane round trip, the staleness bound holds, the owners hold the
@@ -71,12 +72,13 @@ if srv.is_chief:
 print("RESULT " + json.dumps({"index": index, "global_step": gs, "sum": float(m.store.flat.double().sum()),
                               "calls": calls, "lead": lead, "losses": losses, "hist": strat.staleness_hist,
                               "owner_stats": stats, "hbm": report, "depth": strat.depth,
+                              "replica_words": strat.blocks.replicas is not None,
                               "kernel": m.store.variables["dense_1/kernel"].tensor.double().sum().item()}))
 strat.close()
 '''
 
 
-def _run(tmp_path, n, steps, bound):
+def _run(tmp_path, n, steps, bound, words="replica"):
     ports = _ports(n)
     hosts = ",".join("127.0.0.1:%d" % p for p in ports)
     script = tmp_path / "worker.py"
@@ -85,7 +87,8 @@ def _run(tmp_path, n, steps, bound):
     env = dict(os.environ)
     for k in ("JOB_NAME", "TASK_INDEX", "PS_HOSTS", "WORKER_HOSTS", "RANK", "WORLD_SIZE", "LOCAL_RANK", "DTF_COMM_BACKEND"):
         env.pop(k, None)
-    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", PYTHONFAULTHANDLER="1")
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", PYTHONFAULTHANDLER="1",
+               DTF_DOORBELL_KERNELS="1" if words == "replica" else "0")
     procs = [subprocess.Popen([sys.executable, str(script), str(i), hosts, str(steps), str(bound), ckpt], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for i in range(n)]
     results = []
@@ -103,10 +106,12 @@ def _run(tmp_path, n, steps, bound):
     return results, ckpt
 
 
-@pytest.mark.parametrize("n,bound", [(2, 2), (4, 3), (2, 0)])
-def test_ranks_sharing_the_gpu_train_through_peer_regions(tmp_path, n, bound):
+@pytest.mark.parametrize("n,bound,words", [(2, 2, "replica"), (4, 3, "replica"), (2, 0, "replica"), (3, 2, "shm")])
+def test_ranks_sharing_the_gpu_train_through_peer_regions(tmp_path, n, bound, words):
     steps = 30
-    results, ckpt = _run(tmp_path, n, steps, bound)
+    results, ckpt = _run(tmp_path, n, steps, bound, words)
+    from distributed_tensorflow_amd.parallel.doorbell import ControlBlocks
+    assert all(r["replica_words"] == (words == "replica" and ControlBlocks.replica_mode_available("cuda:0")) for r in results)
     assert all(r["global_step"] == n * steps for r in results)
     assert len({round(r["sum"], 5) for r in results}) == 1               # everybody pulled the same variables
     # steady state: no control-plane round trip inside a step
