@@ -464,26 +464,27 @@ __global__ __launch_bounds__(256) void pad_nhwc_scalar_kernel(const float* __res
     }
 }
 
-// rowtab[(b*OH + oh)*OW + ow] = ((b*Hp + oh)*Wp + ow) * C : origin of the patch of output pixel (b, oh, ow)
+// rowtab[(b*OH + oh)*OW + ow] = ((b*Hp + oh*sy)*Wp + ow*sx) * C : origin of the patch of output pixel (b, oh, ow) of a
+// convolution with strides (sy, sx)
 __global__ __launch_bounds__(256) void conv_rowtab_kernel(int* __restrict__ rowtab, int B, int OH, int OW, int Hp, int Wp,
-                                                          int C, long long total) {
+                                                          int C, int sy, int sx, long long total) {
     for (long long m = (long long)blockIdx.x * 256 + threadIdx.x; m < total; m += (long long)gridDim.x * 256) {
         const int ow = (int)(m % OW);
         const int oh = (int)((m / OW) % OH);
         const int b = (int)(m / ((long long)OW * OH));
-        rowtab[m] = (int)((((long long)b * Hp + oh) * Wp + ow) * C);
+        rowtab[m] = (int)((((long long)b * Hp + oh * sy) * Wp + ow * sx) * C);
     }
 }
 
-// Tables for gathering patches from an UNPADDED image: rowtab[m] = ((b*H + oh - pt)*W + (ow - pl)) * C, the origin of
-// the window of output pixel m = (b, oh, ow) - negative at the top / left border - and bit ky*KW + kx of masktab[m] set
-// iff input pixel (oh - pt + ky, ow - pl + kx) exists.  Taps outside the image then read as zero inside the GEMM loader,
+// Tables for gathering patches from an UNPADDED image: rowtab[m] = ((b*H + oh*sy - pt)*W + (ow*sx - pl)) * C, the origin
+// of the window of output pixel m = (b, oh, ow) - negative at the top / left border - and bit ky*KW + kx of masktab[m]
+// set iff input pixel (oh*sy - pt + ky, ow*sx - pl + kx) exists.  Taps outside the image then read as zero inside the GEMM loader,
 // and no zero-padded copy of the image is ever written.
 // pool_order: rows are numbered window by window of a 2x2 pooling over the output, m = ((b*OH/2 + py)*OW/2 + px)*4 +
 // 2*dy + dx for output pixel (2py + dy, 2px + dx), so that four consecutive GEMM rows are one pooling window.
 __global__ __launch_bounds__(256) void conv_rowtab_masked_kernel(int* __restrict__ rowtab, unsigned* __restrict__ masktab, int B,
                                                                  int OH, int OW, int H, int W, int KH, int KW, int pt, int pl,
-                                                                 int C, int pool_order, long long total) {
+                                                                 int C, int pool_order, int sy, int sx, long long total) {
     for (long long m = (long long)blockIdx.x * 256 + threadIdx.x; m < total; m += (long long)gridDim.x * 256) {
         int ow, oh, b;
         if (pool_order) {
@@ -498,11 +499,11 @@ __global__ __launch_bounds__(256) void conv_rowtab_masked_kernel(int* __restrict
             oh = (int)((m / OW) % OH);
             b = (int)(m / ((long long)OW * OH));
         }
-        rowtab[m] = (int)((((long long)b * H + (oh - pt)) * W + (ow - pl)) * C);
+        rowtab[m] = (int)((((long long)b * H + (oh * sy - pt)) * W + (ow * sx - pl)) * C);
         unsigned mk = 0;
         for (int ky = 0; ky < KH; ++ky)
             for (int kx = 0; kx < KW; ++kx) {
-                const int h = oh - pt + ky, w = ow - pl + kx;
+                const int h = oh * sy - pt + ky, w = ow * sx - pl + kx;
                 if (h >= 0 && h < H && w >= 0 && w < W) mk |= 1u << (ky * KW + kx);
             }
         masktab[m] = mk;
@@ -540,22 +541,23 @@ DTF_API int dtf_conv_pad(const float* src, float* dst, int B, int H, int W, int 
 }
 
 DTF_API int dtf_conv_rowtab_masked(int* rowtab, unsigned* masktab, int B, int OH, int OW, int H, int W, int KH, int KW, int pt,
-                                   int pl, int C, int pool_order, hipStream_t stream) {
+                                   int pl, int C, int pool_order, int sy, int sx, hipStream_t stream) {
     if (B <= 0 || OH <= 0 || OW <= 0 || H <= 0 || W <= 0 || C <= 0 || KH <= 0 || KW <= 0 || KH * KW > 32) return -3;
+    if (sy < 1 || sx < 1) return -3;
     if (pool_order && (OH % 2 != 0 || OW % 2 != 0)) return -3;
     if ((long long)B * H * W * C >= (1ll << 30)) return -8;      // byte offsets of the gather are 32-bit
     const long long total = (long long)B * OH * OW;
     hipLaunchKernelGGL(conv_rowtab_masked_kernel, dim3(grid_for(total)), dim3(256), 0, stream, rowtab, masktab, B, OH, OW, H, W,
-                       KH, KW, pt, pl, C, pool_order, total);
+                       KH, KW, pt, pl, C, pool_order, sy, sx, total);
     DTF_CHECK_LAUNCH();
     return 0;
 }
 
-DTF_API int dtf_conv_rowtab(int* rowtab, int B, int OH, int OW, int Hp, int Wp, int C, hipStream_t stream) {
-    if (B <= 0 || OH <= 0 || OW <= 0 || Hp < OH || Wp < OW || C <= 0) return -3;
+DTF_API int dtf_conv_rowtab(int* rowtab, int B, int OH, int OW, int Hp, int Wp, int C, int sy, int sx, hipStream_t stream) {
+    if (B <= 0 || OH <= 0 || OW <= 0 || sy < 1 || sx < 1 || Hp < (OH - 1) * sy + 1 || Wp < (OW - 1) * sx + 1 || C <= 0) return -3;
     if ((long long)B * Hp * Wp * C >= (1ll << 31)) return -8;
     const long long total = (long long)B * OH * OW;
-    hipLaunchKernelGGL(conv_rowtab_kernel, dim3(grid_for(total)), dim3(256), 0, stream, rowtab, B, OH, OW, Hp, Wp, C, total);
+    hipLaunchKernelGGL(conv_rowtab_kernel, dim3(grid_for(total)), dim3(256), 0, stream, rowtab, B, OH, OW, Hp, Wp, C, sy, sx, total);
     DTF_CHECK_LAUNCH();
     return 0;
 }

@@ -363,8 +363,9 @@ class Conv2D(Layer):
         cols = self._buf.get("cols", (B * OH * OW, kh * kw * C), x.device)
         return F.im2col(x, kh, kw, self.strides, self.padding, out=cols)
 
-    # ---- implicit-GEMM path (GPU, stride 1, 4-channel multiples): the GEMM kernels gather patch rows straight from
-    #      a zero-padded copy of the image, so no [B*OH*OW, kh*kw*cin] matrix ever exists in HBM
+    # ---- implicit-GEMM path (GPU, 4-channel multiples, any strides): the GEMM kernels gather patch rows straight from
+    #      the image, so no [B*OH*OW, kh*kw*cin] patch matrix ever exists in HBM for the forward pass and the filter
+    #      gradient; the data gradient is gathered the same way at stride 1 and goes through col2im otherwise
     def _implicit(self, x) -> bool:
         if not x.is_cuda or self.kernel_size == (1, 1):
             return False
@@ -386,16 +387,17 @@ class Conv2D(Layer):
             g = {"pt": pt, "pl": pl, "Hp": Hp, "Wp": Wp,
                  "masked": self._masked_tables_fit(B, H, W, C, OH, OW, self.filters, kh, kw, self.need_input_grad)}
             if g["masked"]:
-                g["rowtab"], g["shift"], g["mask"] = F.conv_tables_unpadded(B, OH, OW, H, W, kh, kw, pt, pl, C, x.device)
-                if self._pool_in_epilogue_ok(OH, OW):
+                g["rowtab"], g["shift"], g["mask"] = F.conv_tables_unpadded(B, OH, OW, H, W, kh, kw, pt, pl, C, x.device,
+                                                                            strides=self.strides)
+                if self.strides == (1, 1) and self._pool_in_epilogue_ok(OH, OW):
                     # same patches, numbered pooling window by pooling window: the forward GEMM pools in its epilogue
                     g["rowtab_pool"], _, g["mask_pool"] = F.conv_tables_unpadded(B, OH, OW, H, W, kh, kw, pt, pl, C,
                                                                                  x.device, pool_order=True)
             else:
                 g["xpad"] = torch.empty((B, Hp, Wp, C), dtype=torch.float32, device=x.device)
-                g["rowtab"], g["shift"] = F.conv_tables(B, OH, OW, Hp, Wp, kh, kw, C, x.device)
+                g["rowtab"], g["shift"] = F.conv_tables(B, OH, OW, Hp, Wp, kh, kw, C, x.device, strides=self.strides)
                 g["mask"] = None
-            if self.need_input_grad:
+            if self.need_input_grad and self.strides == (1, 1):
                 N = self.filters
                 g["top"], g["left"], g["Hq"], g["Wq"] = kh - 1 - pt, kw - 1 - pl, H + kh - 1, W + kw - 1
                 if g["masked"]:
@@ -534,6 +536,11 @@ class Conv2D(Layer):
                               masktab=g["mask"])
             if not self.need_input_grad:
                 return None
+            if self.strides != (1, 1):
+                # strided: the patch gradients dz . W^T, scattered back (overlapping windows summed) by col2im
+                dcols = F.dense_backward_dx(dz, self.kernel.tensor.view(-1, Fo), out=self._buf.get("dcols", (M, K), x.device))
+                dx = self._buf.get("dx", x.shape, x.device)
+                return F.col2im(dcols, x.shape, kh, kw, self.strides, self.padding, x if self.fuse_prev_relu else None, out=dx)
             B, H, W, C = x.shape
             OH, OW, _ = self.output_shape
             dz4 = dz.view(B, OH, OW, Fo)

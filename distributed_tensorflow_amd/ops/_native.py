@@ -90,9 +90,9 @@ def kernels():
         "dtf_conv_pool_wgrad": [c_p] * 6 + [c_i] * 12 + [c_p, c_p],
         "dtf_maxpool_bwd": [c_p, c_p, c_p, c_p] + [c_i] * 7 + [c_p],
         "dtf_conv_pad": [c_p, c_p] + [c_i] * 8 + [c_p],
-        "dtf_conv_rowtab": [c_p] + [c_i] * 6 + [c_p],
+        "dtf_conv_rowtab": [c_p] + [c_i] * 8 + [c_p],
         "dtf_conv_flip_weights": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
-        "dtf_conv_rowtab_masked": [c_p, c_p] + [c_i] * 11 + [c_p],
+        "dtf_conv_rowtab_masked": [c_p, c_p] + [c_i] * 13 + [c_p],
         "dtf_conv_gemm_fwd": [c_p, c_ll, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p],
         "dtf_conv_gemm_dgrad": [c_p, c_ll, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p],
         "dtf_conv_gemm_wgrad": [c_p, c_ll, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p],

@@ -864,11 +864,13 @@ def mlp_tail(h1, w2, b2, w3, b3, labels, dz1, dw2, db2, dw3, db3, workspace, kee
 
 # ----------------------------------------------------------------------------- implicit-GEMM convolution (GPU, stride 1)
 def conv_implicit_supported(c_in: int, c_out: int, strides, need_dgrad: bool = True) -> bool:
-    """The GEMM kernels can gather patch rows straight from the image (no patch matrix in HBM) when the stride is 1
-    and a 4-float vector lies inside one window position: ``c_in % 4 == 0`` (and ``c_out % 4 == 0`` for the data
-    gradient, which is a convolution over the output gradient).  Multiples of 32 channels take the loaders' fast path
-    (a whole 32-deep k tile inside one window position)."""
-    return tuple(strides) == (1, 1) and c_in % 4 == 0 and (not need_dgrad or c_out % 4 == 0) and nv.kernels_available() \
+    """The GEMM kernels can gather patch rows straight from the image (no patch matrix in HBM) when a 4-float vector
+    lies inside one window position: ``c_in % 4 == 0``, any strides (forward and filter gradient).  The data gradient
+    is gathered the same way - a convolution over the output gradient, ``c_out % 4 == 0`` - at stride 1; a strided
+    layer computes it as a patch-gradient product scattered back by ``col2im``.  Multiples of 32 channels take the
+    loaders' fast path (a whole 32-deep k tile inside one window position)."""
+    unit = tuple(strides) == (1, 1)
+    return c_in % 4 == 0 and (not need_dgrad or not unit or c_out % 4 == 0) and nv.kernels_available() \
         and hasattr(nv.kernels(), "dtf_conv_gemm_fwd")
 
 
@@ -883,11 +885,11 @@ def conv_pad(x, pt: int, pl: int, Hp: int, Wp: int, out=None):
     return out
 
 
-def conv_tables(B: int, OH: int, OW: int, Hp: int, Wp: int, KH: int, KW: int, C: int, device):
+def conv_tables(B: int, OH: int, OW: int, Hp: int, Wp: int, KH: int, KW: int, C: int, device, strides=(1, 1)):
     """``(rowtab, shift)``: element offset of every output pixel's patch origin in the padded image, and of every
     window position relative to that origin."""
     rowtab = torch.empty(B * OH * OW, dtype=torch.int32, device=device)
-    rc = nv.kernels().dtf_conv_rowtab(nv.ptr(rowtab), B, OH, OW, Hp, Wp, C, nv.stream_ptr())
+    rc = nv.kernels().dtf_conv_rowtab(nv.ptr(rowtab), B, OH, OW, Hp, Wp, C, int(strides[0]), int(strides[1]), nv.stream_ptr())
     nv.check(rc, "dtf_conv_rowtab")
     kh = torch.arange(KH, dtype=torch.int32).view(KH, 1)
     kw = torch.arange(KW, dtype=torch.int32).view(1, KW)
@@ -896,7 +898,7 @@ def conv_tables(B: int, OH: int, OW: int, Hp: int, Wp: int, KH: int, KW: int, C:
 
 
 def conv_tables_unpadded(B: int, OH: int, OW: int, H: int, W: int, KH: int, KW: int, pt: int, pl: int, C: int, device,
-                         pool_order: bool = False):
+                         pool_order: bool = False, strides=(1, 1)):
     """``(rowtab, shift, masktab)`` for gathering patches from an image that is NOT zero-padded: window origins (negative
     at the top / left border), window-position offsets, and per output pixel the bit set of window positions that lie
     inside the image (the GEMM loader reads the others as zero).  Needs ``KH * KW <= 32``.  ``pool_order`` numbers the
@@ -904,7 +906,7 @@ def conv_tables_unpadded(B: int, OH: int, OW: int, H: int, W: int, KH: int, KW: 
     rowtab = torch.empty(B * OH * OW, dtype=torch.int32, device=device)
     masktab = torch.empty(B * OH * OW, dtype=torch.int32, device=device)
     rc = nv.kernels().dtf_conv_rowtab_masked(nv.ptr(rowtab), nv.ptr(masktab), B, OH, OW, H, W, KH, KW, pt, pl, C,
-                                             int(pool_order), nv.stream_ptr())
+                                             int(pool_order), int(strides[0]), int(strides[1]), nv.stream_ptr())
     nv.check(rc, "dtf_conv_rowtab_masked")
     kh = torch.arange(KH, dtype=torch.int32).view(KH, 1)
     kw = torch.arange(KW, dtype=torch.int32).view(1, KW)

@@ -247,3 +247,74 @@ def test_general_max_pooling_kernels_match_the_cpu_path(gpu_device, pool, stride
         dxg = F.maxpool_strided_backward(dy.to(gpu_device), argg, x.shape, pool, strides, padding,
                                          x_relu=None if relu is None else relu.to(gpu_device))
         torch.testing.assert_close(dxg.cpu(), dx, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("g", [
+    dict(B=3, H=9, W=11, C=8, N=12, KH=3, KW=3, strides=(2, 2), padding="same"),
+    dict(B=2, H=12, W=10, C=32, N=16, KH=5, KW=5, strides=(2, 1), padding="valid"),
+    dict(B=4, H=8, W=8, C=4, N=8, KH=2, KW=2, strides=(2, 2), padding="valid"),
+    dict(B=2, H=13, W=13, C=12, N=20, KH=7, KW=7, strides=(3, 3), padding="same"),     # 49 taps: the padded-copy tables
+])
+def test_strided_implicit_gemm_conv_matches_patch_matrix_path(gpu_device, g):
+    """Strided convolutions gather their patches inside the GEMM too (forward and filter gradient): window origins step
+    by the strides, in the unpadded (bit set of in-image taps) and in the padded-copy form of the tables."""
+    gen = torch.Generator().manual_seed(8)
+    B, H, W, C, N, KH, KW = (g[k] for k in ("B", "H", "W", "C", "N", "KH", "KW"))
+    st, pad = g["strides"], g["padding"]
+    assert F.conv_implicit_supported(C, N, st)
+    x = torch.randn(B, H, W, C, generator=gen).to(gpu_device)
+    w = (torch.randn(KH, KW, C, N, generator=gen) * 0.1).to(gpu_device)
+    b = torch.randn(N, generator=gen).to(gpu_device)
+    OH, OW, pt, pl, pb, pr = F.conv_geometry(H, W, KH, KW, st, pad)
+    M, K = B * OH * OW, KH * KW * C
+    cols = F.im2col(x, KH, KW, st, pad)
+    y_ref = F.dense_forward(cols, w.view(K, N), b, F.ACT_RELU)
+    dz = torch.randn(M, N, generator=gen).to(gpu_device)
+    dw_ref, db_ref = torch.empty(K, N, device=gpu_device), torch.empty(N, device=gpu_device)
+    F.dense_backward_dw(cols, dz, dw_ref, db_ref)
+    ws = torch.empty(max(F.dense_dw_workspace_floats(M, N, K), 1), device=gpu_device)
+    forms = []
+    if KH * KW <= 32:
+        rowtab, shift, mask = F.conv_tables_unpadded(B, OH, OW, H, W, KH, KW, pt, pl, C, gpu_device, strides=st)
+        forms.append((x, rowtab, shift, mask))
+    Hp, Wp = H + pt + pb, W + pl + pr
+    rowtab, shift = F.conv_tables(B, OH, OW, Hp, Wp, KH, KW, C, gpu_device, strides=st)
+    forms.append((F.conv_pad(x, pt, pl, Hp, Wp), rowtab, shift, None))
+    for src, rowtab, shift, mask in forms:
+        y = F.conv_gemm_forward(src, rowtab, shift, w.view(K, N), b, F.ACT_RELU, torch.empty(M, N, device=gpu_device),
+                                masktab=mask)
+        torch.testing.assert_close(y, y_ref, rtol=1e-4, atol=1e-4)
+        dw, db = torch.full((K, N), float("nan"), device=gpu_device), torch.full((N,), float("nan"), device=gpu_device)
+        F.conv_gemm_wgrad(src, rowtab, shift, dz, dw, db, ws, masktab=mask)
+        torch.testing.assert_close(dw, dw_ref, rtol=1e-3, atol=1e-3)
+        torch.testing.assert_close(db, db_ref, rtol=1e-3, atol=1e-3)
+
+
+def test_cnn_with_strided_convs_matches_autograd(gpu_device):
+    """Strided layers in a model: implicit forward / filter gradient, data gradient through col2im; against autograd."""
+    from distributed_tensorflow_amd.layers import Conv2D, Dense, Flatten
+    from distributed_tensorflow_amd.models import Sequential
+
+    def build():
+        return Sequential([
+            Conv2D(8, (3, 3), strides=(2, 2), padding="same", activation="relu", input_shape=(11, 11, 4)),
+            Conv2D(12, (3, 3), strides=(2, 1), padding="valid", activation="relu"),
+            Conv2D(8, (2, 2), padding="same", activation="relu"),
+            Flatten(),
+            Dense(5, activation="softmax"),
+        ])
+    m = build()
+    m.compile(loss="sparse_categorical_crossentropy", optimizer="sgd", metrics=["accuracy"], device=gpu_device, seed=3)
+    gen = torch.Generator().manual_seed(6)
+    x = torch.randn(6, 11, 11, 4, generator=gen)
+    y = torch.randint(0, 5, (6,), generator=gen)
+    m.compute_gradients(x.to(gpu_device), y.to(gpu_device))
+    from distributed_tensorflow_amd.layers import Conv2D as C2
+    assert [c._used_implicit for c in m.layers if isinstance(c, C2)] == [True, True, True]
+    host = build()
+    host.compile(loss="sparse_categorical_crossentropy", optimizer="sgd", device="cpu", seed=3)
+    host.store.flat.copy_(m.store.flat.cpu())
+    ref_loss, params = _autograd_reference(host, x, y)
+    assert m.read_stats()["loss"] == pytest.approx(ref_loss, rel=1e-4)
+    for v, p in zip(m.store.trainable, params):
+        torch.testing.assert_close(v.grad.cpu(), p.grad, rtol=2e-3, atol=2e-5, msg=v.name)
