@@ -164,9 +164,8 @@ def test_elastic_worker_is_restarted_alone_and_readmitted(tmp_path, victim, stal
     elastic_run(tmp_path, victim, staleness, _env({}))
 
 
-def elastic_run(tmp_path, victim, staleness, base_env):
+def elastic_run(tmp_path, victim, staleness, base_env, last_step=9000):
     log_dir, run_dir = str(tmp_path / "logs"), str(tmp_path / "run")
-    last_step = 9000
     env = dict(base_env, DTF_HEARTBEAT_MAX_AGE_SECS="1.5", DTF_HEARTBEAT_ABORT_SECS="2", DTF_HEARTBEAT_SECS="0.2",
                PYTHONPATH=ROOT)
     launcher = subprocess.Popen(

@@ -78,7 +78,8 @@ def test_elastic_worker_is_readmitted_on_the_gpu(tmp_path):
     """1 ps + 2 workers on the one GPU, variables in the ps task's hipIpc-mapped region: a killed worker is restarted
     alone, maps the owner's region again and continues its doorbell lane while the others keep training."""
     from .test_failure import elastic_run
-    elastic_run(tmp_path, "worker:1", "3", _env({"HSA_ENABLE_IPC_MODE_LEGACY": "0"}))
+    # (a long budget: on the GPU the cluster takes ten thousand steps a second, and the fault has to land mid-run)
+    elastic_run(tmp_path, "worker:1", "3", _env({"HSA_ENABLE_IPC_MODE_LEGACY": "0"}), last_step=120000)
 
 
 @pytest.mark.parametrize("allreduce", ["rccl", "p2p"])
