@@ -9,9 +9,9 @@
 //   worker w, step t                                      owner j
 //   ----------------                                      -------
 //   put grad shard -> inbox[w][t % D]   (stream copy)
-//   host function on that stream:                         pump thread sees lane[w].door > consumed[w]
+//   behind it on that stream (kernel / host function):    pump thread sees lane[w].door > consumed[w]
 //       lane[w].pull_version[t % D] = version pulled        apply kernel on the owner's stream (var, m, v in its HBM)
-//       lane[w].door = t + 1                                host function on that stream:
+//       lane[w].door = t + 1                                behind it on that stream (kernel / host function):
 //                                                               lane[w].ack_version[t % D] = version after the apply
 //   (before reusing inbox[w][(t+D) % D]:                        ctl.version, ctl.global_step, lane[w].ack = t + 1
 //    wait until lane[w].ack > t)

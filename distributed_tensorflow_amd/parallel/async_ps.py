@@ -18,9 +18,10 @@ Re-designed for one MI355X node:
   variables across all eight HBMs and nobody else holds optimizer state.  The data plane is one-sided and stays
   on the devices: a worker *puts* its gradient shard into the owner's inbox slot through peer-mapped memory over
   xGMI (``peer_region.PeerRegion``: hipIpc on GPUs, POSIX shared memory on CPUs) and rings a doorbell word from a
-  host function queued behind the copies; the owner's native service thread (``csrc/kernels/owner_pump.hip``)
-  launches the fused apply kernel on its own stream and acknowledges through the same words
-  (``parallel/doorbell.py``); a worker *gets* the owners' variable shards straight into its flat buffer at the
+  kernel queued behind the copies; the owner's native service thread (``csrc/kernels/owner_pump.hip``)
+  launches the fused apply kernel on its own stream and an acknowledgement kernel behind it (``parallel/doorbell.py``:
+  the words are replicas in every rank's device memory, polled by the local CPU; host-written shared memory on
+  CPUs); a worker *gets* the owners' variable shards straight into its flat buffer at the
   start of a step.  A step makes no control-plane round trip and never waits for a stream on the host; with
   two inbox slots per worker the next forward pass starts while the owners are still applying (that lag is
   part of the staleness bound).  Version, staleness, ``global_step`` and the workers' clocks ride in the words;
@@ -28,7 +29,9 @@ Re-designed for one MI355X node:
   round-robin or byte-balanced).  On one node, with ps tasks and workers on the same kind of device, they use the
   same one-sided plane: every ps task allocates a region (its packed variables, two slot planes, inbox slots),
   workers put the flat ranges of an owner's variables into their inbox slot and get them back from its variable
-  plane, doorbells and the native pump do the rest - no process group, no socket on the step path;
+  plane, doorbells and the native pump do the rest - no process group, no socket on the step path; for the
+  reference network at a batch of at most 64 a worker's whole step is one kernel that reads the variables from and
+  writes the gradients into the ps tasks' memory and rings the doorbells itself (``train_step_direct``);
 * ps tasks on other nodes, or on another kind of device than their workers (``DTF_PS_DATA_PLANE=p2p`` forces it):
   one packed gradient message to and one packed parameter message from every owner per step over
   ``torch.distributed`` send/recv - RCCL between GPUs, gloo between CPU processes - instead of TF's one RecvTensor

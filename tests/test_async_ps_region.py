@@ -92,7 +92,7 @@ def test_two_ps_tasks_two_workers(tmp_path, plane):
 @pytest.mark.gpu
 def test_two_ps_tasks_two_workers_share_the_gpu(tmp_path):
     """The same cluster with all four tasks on one MI355X: hipIpc-mapped regions, the pump's apply kernels on the ps
-    tasks' streams, doorbells rung from host functions behind the workers' copies."""
+    tasks' streams, doorbells rung by kernels behind the workers' copies."""
     env = dict(os.environ)
     for k in ("JOB_NAME", "TASK_INDEX", "PS_HOSTS", "WORKER_HOSTS"):
         env.pop(k, None)
