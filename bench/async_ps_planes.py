@@ -26,7 +26,8 @@ srv = Server(ClusterSpec({"ps": ps_hosts, "worker": w_hosts}), job, index, confi
 if job == "ps":
     srv.join()
     sys.exit(0)
-strat = AsyncPSStrategy(srv, max_staleness=None)
+ms = os.environ.get("MAX_STALENESS", "")
+strat = AsyncPSStrategy(srv, max_staleness=int(ms) if ms else None)
 m = xor_mlp()
 m.compile(loss="mean_squared_error", optimizer="adam", metrics=["accuracy"], strategy=strat, device=device, seed=index)
 g = torch.Generator().manual_seed(index)
