@@ -622,13 +622,11 @@ __global__ __launch_bounds__(NT, 1) void mlp3_fused_kernel(const FusedArgs p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __threadfence_system();
         __syncthreads();
-        if (tid0 < p.ring_count) {      // thread i rings owner i, in every replica: pull_version[slot], clock, then the door
+        if (tid0 < p.ring_count) {      // thread i rings owner i, in every replica it was given: pull_version[slot], then the door
             const long long lw = p.ring_lane_word[tid0];
-            for (int r = 0; r < p.ring_world; ++r) {
-                unsigned long long* ln = p.ring_rep[r] + lw;
-                __hip_atomic_store(ln + 2 + p.ring_slot, pulled_version, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                if (tid0 == 0) __hip_atomic_store(ln + 1, p.ring_clock, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
+            for (int r = 0; r < p.ring_world; ++r)      // (the clock is published by owner 0 with its acknowledgement)
+                __hip_atomic_store(p.ring_rep[r] + lw + 2 + p.ring_slot, pulled_version, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_SYSTEM);
             __threadfence_system();
             for (int r = 0; r < p.ring_world; ++r)
                 __hip_atomic_store(p.ring_rep[r] + lw, p.ring_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);

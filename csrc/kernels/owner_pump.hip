@@ -138,7 +138,12 @@ __global__ __launch_bounds__(64) void ack_kernel(Replicas reps, long long block_
         unsigned long long* lane = ctl + 16 + 16 * worker;
         word_store(lane + W_ACKV + slot, version);
         word_store(ctl + W_VERSION, version);
-        if (owner0) word_store(ctl + W_GSTEP, gstep);
+        if (owner0) {
+            // owner 0 also publishes the shared step and the worker's clock (its completed pushes): the owners are
+            // the ranks that always hold a current mapping of every replica, a restarted worker's included
+            word_store(ctl + W_GSTEP, gstep);
+            word_store(lane + W_CLOCK, seq);
+        }
         __threadfence_system();
         word_release(lane + W_ACK, seq);
     }
@@ -152,15 +157,12 @@ struct RingArgs {
 };
 
 // Worker: everything queued before this launch on the same stream (the gradient shards in the owners' inboxes) is
-// complete.  Thread i rings owner i, in every replica.
+// complete.  Thread i rings owner i, in every replica it is given (the owners' and the worker's own).
 __global__ __launch_bounds__(64) void ring_kernel(Replicas reps, RingArgs a) {
     const int i = threadIdx.x;
     if (i < a.count) {
-        for (int r = 0; r < reps.world; ++r) {
-            unsigned long long* lane = reps.base[r] + a.lane_word[i];
-            word_store(lane + W_PULLV + a.slot, a.pulled[i]);
-            if (i == 0) word_store(lane + W_CLOCK, a.clock);      // lane_word[0] lies in owner 0's block
-        }
+        // (the worker's clock is published by owner 0 when it acknowledges this gradient: see ack_kernel)
+        for (int r = 0; r < reps.world; ++r) word_store(reps.base[r] + a.lane_word[i] + W_PULLV + a.slot, a.pulled[i]);
         __threadfence_system();
         for (int r = 0; r < reps.world; ++r) word_release(reps.base[r] + a.lane_word[i] + W_DOOR, a.seq);
     }
@@ -398,6 +400,14 @@ DTF_API int dtf_pump_resume(void* h, int resync) {
     p->pause_req.store(0, std::memory_order_release);
     for (int i = 0; i < 600000 && p->paused.load(std::memory_order_acquire); ++i)
         std::this_thread::sleep_for(std::chrono::microseconds(100));
+    return 0;
+}
+
+// Replica mode, pump paused: rank r's control area is now at `base` (a restarted worker's new region).
+DTF_API int dtf_pump_set_replica(void* h, int r, void* base) {
+    auto* p = static_cast<Pump*>(h);
+    if (r < 0 || r >= p->cfg.rep_world || !base || !p->paused.load()) return -2;
+    p->cfg.rep_base[r] = base;
     return 0;
 }
 

@@ -245,6 +245,19 @@ DTF_API int dtf_mbox_open_peer(void* h, int r, const void* handle) {
     return 0;
 }
 
+// Rank `r` has been restarted and allocated a new region: drop the mapping of the old one and map the new handle.
+DTF_API int dtf_mbox_reopen_peer(void* h, int r, const void* handle) {
+    auto* m = static_cast<Mailbox*>(h);
+    if (r < 0 || r >= m->world || r == m->rank) return -2;
+    if (m->opened[r]) {
+        (void)hipDeviceSynchronize();
+        (void)hipIpcCloseMemHandle(m->peer[r]);
+        m->opened[r] = false;
+    }
+    m->peer[r] = nullptr;
+    return dtf_mbox_open_peer(h, r, handle);
+}
+
 // Copies `bytes` from local device memory `src` into rank `peer`'s region at byte offset `dst_off`, on `stream`.
 DTF_API int dtf_mbox_put(void* h, int peer, long long dst_off, const void* src, long long bytes, hipStream_t stream) {
     auto* m = static_cast<Mailbox*>(h);

@@ -584,8 +584,7 @@ def mlp3_fused_grad_direct(x, y, var_ptrs, grad_ptrs, dims, training, want_cat, 
     rc = fn(nv.ptr(x), nv.ptr(y), (C.c_void_p * 6)(*var_ptrs), (C.c_void_p * 6)(*grad_ptrs), int(dims[0]), int(dims[1]),
             int(dims[2]), int(dims[3]), batch, int(bool(training)), int(bool(want_cat)), float(keep1), float(keep2),
             int(seed1) & _M32, int(seed2) & _M32, C.c_void_p(step_address), nv.ptr(stats),
-            blocks._rep_array if n else None, blocks.world if n else 0, blocks.rank if n else 0, bw, lw, n, int(slot),
-            int(seq), int(clock), nv.stream_ptr())
+            *(blocks.ring_array() if n else (None, 0, 0)), bw, lw, n, int(slot), int(seq), int(clock), nv.stream_ptr())
     nv.check(rc, "dtf_mlp3_fused_grad_direct")
 
 

@@ -527,6 +527,23 @@ class ParameterServerService:
                 self._reply(w, st, self.owner_index == 0, seq)
                 if self.n:
                     self._send_params(w, wr)
+            elif op == "rejoin_map":
+                # a restarted worker has allocated a new region: with replicated control words this owner maps it, points
+                # its acknowledgements at the new replica and copies its block there (the dead process's mapping goes)
+                if self.blocks is not None and self.blocks.replicas is not None:
+                    self._quiesce()
+                    try:
+                        self.region.remap_peer(wr, self.cp0)
+                        addr = self.blocks.replace_replica(wr)
+                        if self.pump is not None:
+                            self.pump.set_replica(wr, addr)
+                        self.blocks.copy_block_to(wr, self.owner_index)
+                    finally:
+                        self._release()
+                self.cp0.add("%s/rejoin_map_done/%d" % (self.ns, w), 1)
+            elif op == "clock":
+                self.blocks.set_clock(w, int(req["value"]))
+                self.cp0.add("%s/clock_done/%d" % (self.ns, w), 1)
             elif op == "rejoin":
                 # a restarted worker takes over lane `w`: nothing is in flight from its predecessor once the pump has
                 # drained, so door, acknowledgement and the pump's own count can all move to the agreed number
@@ -879,6 +896,10 @@ class AsyncPSStrategy:
             self.blocks = ControlBlocks(srv.rank, srv.world_size, self.cp0, name=self.ns + "/ctl",
                                         timeout_s=self.timeout_s, lanes=self.num_workers, owner_rank=srv.ps_rank,
                                         rejoin=self._rejoined, region=self.region if replica else None)
+            if replica:
+                # a worker's doorbells go to the owners' replicas and its own; everything a worker READS is written by
+                # the owners, who re-map a restarted worker (so nobody depends on a mapping of another worker)
+                self.blocks.use_ring_ranks([srv.ps_rank(j) for j in range(self.num_owners)] + [srv.rank])
         elif not self.colocated:
             # data plane (after the layout is out: ps tasks join the process group once they have it)
             self.plane = "p2p"
@@ -930,6 +951,11 @@ class AsyncPSStrategy:
         clock, so it starts no further back than the slowest running worker (it must not hold the others to a
         staleness bound measured against steps its predecessor never made)."""
         w, b = self.worker_index, self.blocks
+        # first the owners map this process's new region and bring its replica of the control words up to date
+        # (nothing to do for words in shared memory); only then can this process read them
+        base = self.cp0.add("%s/rejoin_map_done/%d" % (self.ns, w), 0)
+        self._post("rejoin_map")
+        self._wait_counter("%s/rejoin_map_done/%d" % (self.ns, w), base + self.num_owners)
         seq = max(b.door(j, w) for j in range(self.num_owners))
         running = [c for c in (b.clock(i) for i in range(self.num_workers) if i != w) if c < (1 << 59)]
         if running:
@@ -937,9 +963,23 @@ class AsyncPSStrategy:
         base = self.cp0.add("%s/rejoin_done/%d" % (self.ns, w), 0)
         self._post("rejoin", {"seq": seq})
         self._wait_counter("%s/rejoin_done/%d" % (self.ns, w), base + self.num_owners)
-        b.set_clock(w, seq)
+        self._set_clock(seq)
         self.clock = seq
         self._acked = [seq] * self.num_owners
+        import sys
+        sys.stderr.write("worker %d re-admitted at gradient number %d (control words: %s)\n"
+                         % (w, seq, "replicas in device memory" if b.replicas is not None else "shared memory"))
+
+    def _set_clock(self, value: int):
+        """Publish this worker's clock outside a push (re-admission, end of training).  With replicated control words
+        and ps tasks as owners that is owner 0's job: it holds a current mapping of every replica."""
+        b = self.blocks
+        if b.replicas is not None and not self.colocated:
+            base = self.cp0.add("%s/clock_done/%d" % (self.ns, self.worker_index), 0)
+            self._post("clock", {"value": int(value)}, owners=[0])
+            self._wait_counter("%s/clock_done/%d" % (self.ns, self.worker_index), base + 1)
+        else:
+            b.set_clock(self.worker_index, value)
 
     def _choose_plane(self, dev, depth: int) -> dict:
         """Chief, ps tasks as owners: the one-sided plane (peer regions + doorbell words) when every task runs on this
@@ -965,7 +1005,7 @@ class AsyncPSStrategy:
         nmax = max([_ranges_numel(r) for r in self.ranges] + [1])
         from .doorbell import ControlBlocks
         return {"plane": "region", "device": dev.type, "stride": (nmax + 63) // 64 * 64, "depth": depth,
-                "words": "replica" if ControlBlocks.replica_mode_available(dev, self.elastic) else "shm"}
+                "words": "replica" if ControlBlocks.replica_mode_available(dev) else "shm"}
 
     def close(self, grace_s: float = 20.0):
         """End this worker's owner thread: wait for the chief's shutdown request to reach it, and if none comes
@@ -1261,7 +1301,8 @@ class AsyncPSStrategy:
     def min_clock(self) -> int:
         """The slowest worker's clock (pushes completed), as the staleness bound sees it."""
         if self.blocks is not None:
-            return self.blocks.min_clock(skip=self._absent_workers())
+            # (this worker's own clock is self.clock; its word may trail it by the pushes still in flight)
+            return self.blocks.min_clock(skip=self._absent_workers() + (self.worker_index,))
         return self.cp0.clock_min("workers")
 
     #: set by the session's heartbeat hook: the tolerated members (elastic workers) that are silent right now
@@ -1439,7 +1480,7 @@ class AsyncPSStrategy:
         """Every worker calls this once after its last step."""
         if self.blocks is not None:
             self._drain()
-            self.blocks.set_clock(self.worker_index, 1 << 60)       # a finished worker never holds others back
+            self._set_clock(1 << 60)                                # a finished worker never holds others back
         else:
             self.cp0.clock_set("workers", self.worker_index, 1 << 60)
         self.cp0.add("workers_done", 1)

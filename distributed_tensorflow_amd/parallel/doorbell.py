@@ -49,6 +49,7 @@ def _k():
         nv.declare(lib, "dtf_pump_pause", [p])
         nv.declare(lib, "dtf_pump_resume", [p, C.c_int])
         nv.declare(lib, "dtf_pump_error", [p])
+        nv.declare(lib, "dtf_pump_set_replica", [p, C.c_int, p])
         nv.declare(lib, "dtf_pump_stream", [p], p)
         nv.declare(lib, "dtf_pump_histogram", [p, p], None)
         nv.declare(lib, "dtf_pump_stop", [p])
@@ -90,8 +91,9 @@ class ControlBlocks:
       rank holds a replica of ALL blocks in the last ``area_floats(world, lanes)`` floats of its peer region - its own
       device memory, which its CPU reads through the large BAR - and every update is stored into all replicas by a
       kernel (``ring`` / the pump's acknowledgement / ``_broadcast``), in stream order behind the data it announces.
-      A process cannot be re-admitted in this mode (nobody would map its new region), so elastic clusters use the
-      shared-memory home."""
+      A worker writes only into the owners' replicas and its own (``ring_array``); the owners write into everybody's,
+      and they are the ones that map a restarted worker's new region (``replace_replica`` / ``copy_block_to``), which
+      is why the workers' clocks are published by owner 0 with its acknowledgements rather than by the workers."""
 
     @staticmethod
     def area_floats(world: int, lanes: Optional[int] = None) -> int:
@@ -99,9 +101,9 @@ class ControlBlocks:
         return 2 * int(world) * (_HDR_WORDS + _LANE_WORDS * int(world if lanes is None else lanes))
 
     @staticmethod
-    def replica_mode_available(device, elastic: bool = False) -> bool:
+    def replica_mode_available(device) -> bool:
         import os
-        if torch.device(device).type != "cuda" or elastic or os.environ.get("DTF_DOORBELL_KERNELS", "1") == "0":
+        if torch.device(device).type != "cuda" or os.environ.get("DTF_DOORBELL_KERNELS", "1") == "0":
             return False
         with torch.cuda.device(device):
             return bool(_k().dtf_device_large_bar())
@@ -127,6 +129,10 @@ class ControlBlocks:
                 raise RuntimeError("a peer region is not mapped")
             self._rep_array = (C.c_void_p * self.world)(*self.replicas)
             self._device = region.device
+            self._region = region
+            # what a worker's doorbell is written into: the replicas of the owners (who poll it) and its own (which
+            # keeps the version the gradient was computed from for the staleness histogram); ranks in table order
+            self._ring_ranks = None          # set by use_ring_ranks(); default: every replica
             local = self.replicas[self.rank]
             self._base = [local + k * nbytes for k in range(self.world)]
             self._views = [(C.c_uint64 * self._block_words).from_address(b) for b in self._base]
@@ -156,6 +162,34 @@ class ControlBlocks:
         self._base = [C.addressof(C.c_char.from_buffer(s.buf)) for s in self._shms]
         if not rejoin:      # a restarted process maps the blocks of ranks that have been running for a while
             cp.barrier("%s/mapped" % name, self.world, timeout_s=timeout_s)
+
+    # ---- replica mode: which replicas a worker's doorbell goes to, and re-admission of a restarted worker
+    def use_ring_ranks(self, ranks):
+        """Restrict this worker's doorbell writes to the replicas of ``ranks`` (the owners' and its own)."""
+        self._ring_ranks = sorted(set(int(r) for r in ranks))
+        self._ring_array = (C.c_void_p * len(self._ring_ranks))(*[self.replicas[r] for r in self._ring_ranks])
+
+    def ring_array(self):
+        """(array of replica bases, count, index of this rank's own replica in it) for doorbell kernels."""
+        if getattr(self, "_ring_ranks", None):
+            return self._ring_array, len(self._ring_ranks), self._ring_ranks.index(self.rank)
+        return self._rep_array, self.world, self.rank
+
+    def replace_replica(self, r: int):
+        """Rank ``r`` was restarted (its region has been re-mapped): its control area is at a new address."""
+        area = self.area_floats(self.world, self.lanes)
+        self.replicas[r] = self._region.peer_address(r, self._region.sizes[r] - area)
+        self._rep_array[r] = self.replicas[r]
+        return self.replicas[r]
+
+    def copy_block_to(self, r: int, owner: int):
+        """Owner side: bring rank ``r``'s (new, zeroed) replica of this owner's block up to date from the local one."""
+        area = self.area_floats(self.world, self.lanes)
+        k = self._blk(owner)
+        bf = 2 * self._block_words
+        lo = self._region.sizes[self.rank] - area + k * bf
+        self._region.put(r, self._region.sizes[r] - area + k * bf, self._region.local[lo:lo + bf])
+        self._region.sync()
 
     # ---- replica mode: positions inside a control area, in 64-bit words
     def block_word(self, owner: int) -> int:
@@ -273,8 +307,9 @@ def ring(stream_ptr: int, on_gpu: bool, blocks: "ControlBlocks", worker: int, ow
     pv = (C.c_ulonglong * n)(*pulled)
     if blocks.replicas is not None:
         lw = (C.c_longlong * n)(*[blocks.lane_word(j, worker) for j in range(n)])
-        rc = _k().dtf_doorbell_ring(C.c_void_p(stream_ptr or 0), 1, None, blocks._rep_array, blocks.world, lw, pv, n,
-                                    int(slot), int(seq), int(clock))
+        reps, nrep, _ = blocks.ring_array()
+        rc = _k().dtf_doorbell_ring(C.c_void_p(stream_ptr or 0), 1, None, reps, nrep, lw, pv, n, int(slot), int(seq),
+                                    int(clock))
     else:
         la = (C.c_void_p * n)(*[blocks.lane_address(j, worker) for j in range(n)])
         rc = _k().dtf_doorbell_ring(C.c_void_p(stream_ptr or 0), 1 if on_gpu else 0, la, None, 0, None, pv, n, int(slot),
@@ -313,10 +348,11 @@ class PushLink:
         for i, v in enumerate(pulled):
             self._pulled[i] = v
         b = self._blocks
+        reps, nrep, _ = b.ring_array() if b.replicas is not None else (None, 0, 0)
         rc = _k().dtf_link_push(self._h, self._region._h, self._table.handle if self._table is not None else None,
                                 C.c_void_p(cur_stream_ptr or 0), grad.data_ptr(), grad.numel() * 4, int(remote_base) * 4,
-                                int(shard_floats) * 4, self._lanes, b._rep_array if b.replicas is not None else None,
-                                b.world, self._lane_words, self._pulled, self.n, int(slot), int(seq), int(clock))
+                                int(shard_floats) * 4, self._lanes, reps, nrep, self._lane_words, self._pulled, self.n,
+                                int(slot), int(seq), int(clock))
         if rc:
             raise RuntimeError("push to the owners failed (%d)" % rc)
 
@@ -372,6 +408,12 @@ class OwnerPump:
 
     def resume(self, resync: bool = False):
         _k().dtf_pump_resume(self._h, 1 if resync else 0)
+
+    def set_replica(self, r: int, address: int):
+        """Paused pump, replica mode: rank ``r``'s control area moved (a restarted worker)."""
+        rc = _k().dtf_pump_set_replica(self._h, int(r), C.c_void_p(address))
+        if rc:
+            raise RuntimeError("cannot update the pump's replica table (%d)" % rc)
 
     def error(self) -> int:
         return int(_k().dtf_pump_error(self._h)) if self._h else 0

@@ -42,6 +42,7 @@ def _k():
         nv.declare(lib, "dtf_mbox_peer_ptr", [p, C.c_int], p)
         nv.declare(lib, "dtf_mbox_local_handle", [p, p])
         nv.declare(lib, "dtf_mbox_open_peer", [p, C.c_int, p])
+        nv.declare(lib, "dtf_mbox_reopen_peer", [p, C.c_int, p])
         nv.declare(lib, "dtf_mbox_set_peer_bytes", [p, C.c_int, ll])
         nv.declare(lib, "dtf_mbox_put", [p, C.c_int, ll, p, ll, p])
         nv.declare(lib, "dtf_mbox_get", [p, C.c_int, ll, p, ll, p])
@@ -239,6 +240,29 @@ class PeerRegion:
             raise ValueError("offset %d outside rank %d's region" % (off, peer))
         base = _k().dtf_mbox_peer_ptr(self._h, int(peer))
         return None if not base else int(base) + int(off) * 4
+
+    def remap_peer(self, peer: int, cp, timeout_s: float = 60.0):
+        """Rank ``peer`` was restarted and has published the handle of a new region: map that one instead of the dead
+        process's (GPU regions; a CPU segment is mapped anew the same way)."""
+        if self._h is not None:
+            lib = _k()
+            nb = lib.dtf_mbox_handle_bytes()
+            raw = base64.b64decode(cp.get("%s/handle/%d" % (self.name, peer), timeout_s=timeout_s))
+            with torch.cuda.device(self.device):
+                rc = lib.dtf_mbox_reopen_peer(self._h, int(peer), C.create_string_buffer(raw, nb))
+            if rc:
+                raise RuntimeError("hipIpcOpenMemHandle of rank %d's new region failed (%d)" % (peer, rc))
+            lib.dtf_mbox_set_peer_bytes(self._h, int(peer), self.sizes[peer] * 4)
+            return
+        from multiprocessing import resource_tracker, shared_memory
+        shm = shared_memory.SharedMemory(name=cp.get("%s/handle/%d" % (self.name, peer), timeout_s=timeout_s).decode())
+        if shm._name.lstrip("/") not in _CREATED_HERE:
+            try:
+                resource_tracker.unregister(shm._name, "shared_memory")
+            except Exception:
+                pass
+        self._peers_shm.append(shm)
+        self._peer_views[peer] = torch.frombuffer(shm.buf, dtype=torch.float32, count=self.sizes[peer])
 
     def make_ranges(self, ranges) -> RangeTable:
         """Prepare ``ranges`` = ``[(peer, remote_off, local_off, n), ...]`` (floats) for ``move_ranges``."""

@@ -161,7 +161,7 @@ def test_elastic_worker_is_restarted_alone_and_readmitted(tmp_path, victim, stal
     and keep training; the successor continues the dead worker's lanes, does not roll the owners back to a checkpoint,
     and the cluster reaches its step budget.  With a staleness bound the dead worker's clock does not hold the
     survivor back."""
-    elastic_run(tmp_path, victim, staleness, _env({}))
+    assert "control words: shared memory" in elastic_run(tmp_path, victim, staleness, _env({}))
 
 
 def elastic_run(tmp_path, victim, staleness, base_env, last_step=9000):
@@ -206,3 +206,5 @@ def elastic_run(tmp_path, victim, staleness, base_env, last_step=9000):
     ck = latest_checkpoint(log_dir)
     step = int(ck.rsplit("-", 1)[1])
     assert last_step <= step <= last_step + 6, report     # the shared step went on counting: no rollback, no fresh run
+    assert "re-admitted at gradient number" in successor, report
+    return successor

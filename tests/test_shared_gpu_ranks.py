@@ -79,7 +79,11 @@ def test_elastic_worker_is_readmitted_on_the_gpu(tmp_path):
     alone, maps the owner's region again and continues its doorbell lane while the others keep training."""
     from .test_failure import elastic_run
     # (a long budget: on the GPU the cluster takes ten thousand steps a second, and the fault has to land mid-run)
-    elastic_run(tmp_path, "worker:1", "3", _env({"HSA_ENABLE_IPC_MODE_LEGACY": "0"}), last_step=120000)
+    log = elastic_run(tmp_path, "worker:1", "3", _env({"HSA_ENABLE_IPC_MODE_LEGACY": "0"}), last_step=120000)
+    from distributed_tensorflow_amd.parallel.doorbell import ControlBlocks
+    if ControlBlocks.replica_mode_available("cuda:0"):
+        # the owners mapped the successor's new region and brought its replica of the control words up to date
+        assert "control words: replicas in device memory" in log
 
 
 @pytest.mark.parametrize("allreduce", ["rccl", "p2p"])
