@@ -52,30 +52,66 @@ class FeedStager:
             else torch.float32
 
     def put(self, a):
-        t = torch.as_tensor(a)
+        t = a if isinstance(a, torch.Tensor) else torch.as_tensor(a)
         if t.device.type != "cpu":
             return None
         dtype = self._target_dtype(t)
-        if t.numel() == 0 or t.numel() * (8 if dtype == torch.int64 else 4) > self.max_bytes:
+        nbytes = t.numel() * (8 if dtype == torch.int64 else 4)
+        if nbytes == 0 or nbytes > self.max_bytes:
             return None
         key = (tuple(t.shape), dtype)
         ring = self._rings.get(key)
         if ring is None:
-            ring = self._rings[key] = {
-                "host": [torch.empty(t.shape, dtype=dtype).pin_memory() for _ in range(self.depth)],
-                "dev": [torch.empty(t.shape, dtype=dtype, device=self.device) for _ in range(self.depth)],
-                "event": [None] * self.depth, "next": 0}
-        i = ring["next"]
-        ring["next"] = (i + 1) % self.depth
-        if ring["event"][i] is not None:
-            ring["event"][i].synchronize()
-        ring["host"][i].copy_(t)
-        ring["dev"][i].copy_(ring["host"][i], non_blocking=True)
-        ev = ring["event"][i]
-        if ev is None:
-            ev = ring["event"][i] = torch.cuda.Event()
-        ev.record()
-        return ring["dev"][i]
+            ring = self._rings[key] = _FeedRing(t.shape, dtype, nbytes, self.depth, self.device)
+        return ring.push(t)
+
+    def close(self):
+        for ring in self._rings.values():
+            ring.close()
+        self._rings = {}
+
+
+class _FeedRing:
+    """One shape's staging ring; wait, host copy, asynchronous device copy and event record are one native call
+    (``dtf_feed_ring_push``)."""
+
+    def __init__(self, shape, dtype, nbytes, depth, device):
+        import ctypes as C
+        from .ops import _native as nv
+        self._nv, self._C = nv, C
+        self.dtype = dtype
+        self.index = device.index if device.index is not None else torch.cuda.current_device()
+        self.host = [torch.empty(shape, dtype=dtype).pin_memory() for _ in range(depth)]
+        self.dev = [torch.empty(shape, dtype=dtype, device=device) for _ in range(depth)]
+        lib = nv.kernels()
+        self._push = nv.declare(lib, "dtf_feed_ring_push", [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)])
+        self._acquire = nv.declare(lib, "dtf_feed_ring_acquire", [C.c_void_p, C.POINTER(C.c_int)])
+        self._destroy = nv.declare(lib, "dtf_feed_ring_destroy", [C.c_void_p])
+        create = nv.declare(lib, "dtf_feed_ring_create",
+                            [C.c_int, C.c_longlong, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)])
+        hp = (C.c_void_p * depth)(*[h.data_ptr() for h in self.host])
+        dp = (C.c_void_p * depth)(*[d.data_ptr() for d in self.dev])
+        handle = C.c_void_p()
+        nv.check(create(depth, nbytes, hp, dp, C.byref(handle)), "dtf_feed_ring_create")
+        self.handle = handle
+        self._slot = C.c_int(0)
+
+    def push(self, t: torch.Tensor) -> torch.Tensor:
+        stream = torch._C._cuda_getCurrentRawStream(self.index)
+        if t.dtype == self.dtype and t.is_contiguous():
+            src = t.data_ptr()
+        else:
+            # dtype conversion (float64 / integer arrays): written into the pinned buffer by the tensor library
+            self._nv.check(self._acquire(self.handle, self._slot), "dtf_feed_ring_acquire")
+            self.host[self._slot.value].copy_(t)
+            src = None
+        self._nv.check(self._push(self.handle, src, stream, self._slot), "dtf_feed_ring_push")
+        return self.dev[self._slot.value]
+
+    def close(self):
+        if self.handle is not None:
+            self._destroy(self.handle)
+            self.handle = None
 
 
 class ModelEngine:
@@ -221,7 +257,7 @@ class ModelEngine:
         dev = self.model.device
         if isinstance(a, (tuple, list)) and a and all(isinstance(t, torch.Tensor) for t in a):
             return tuple(self._to_device(t) for t in a)      # a model with several fed placeholders
-        if dev.type == "cuda" and not isinstance(a, torch.Tensor):
+        if dev.type == "cuda" and not (isinstance(a, torch.Tensor) and a.is_cuda):
             stager = getattr(self, "_stager", None)
             if stager is None:
                 stager = self._stager = FeedStager(dev)

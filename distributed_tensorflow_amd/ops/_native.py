@@ -135,8 +135,10 @@ def kernels_available() -> bool:
 
 
 def stream_ptr() -> int:
-    """Raw hipStream_t of the current PyTorch stream (the capture stream under graph capture)."""
-    return torch.cuda.current_stream().cuda_stream
+    """Raw hipStream_t of the current PyTorch stream (the capture stream under graph capture).  Every native op asks
+    for it: the binding's own entry point is used, `torch.cuda.current_stream()` builds a Python stream object and
+    resolves the device through several layers, ~3 us per call."""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 def ptr(t) -> int:

@@ -82,13 +82,15 @@ def test_one_ps_two_workers(tmp_path, mode):
     ck = latest_checkpoint(str(tmp_path))
     assert ck is not None
     step = int(ck.rsplit("-", 1)[1])
-    assert 120 <= step <= 124          # shared global_step: the budget is cluster-wide, workers may overshoot by one each
+    # shared global_step: the budget is cluster-wide; each worker may have two gradients in the owners' inbox slots and
+    # one more computed against a counter it read before those were applied
+    assert 120 <= step <= 126
     names = dict(list_variables(ck))
     assert names["dense_1/kernel"] == (64, 128) and names["global_step"] == ()
     assert "dense_3/kernel/Adam_1" in names
     with BundleReader(ck) as r:
-        # asynchronous mode: the other worker's push may land between the chief reading global_step for the file name
+        # asynchronous mode: the other worker's pushes (two inbox slots) may land between the chief reading global_step for the file name
         # and the owner snapshotting its shard (TensorFlow's SaveV2 on a live parameter server has the same window)
-        assert step <= int(r.get_tensor("global_step").item()) <= step + 1
+        assert step <= int(r.get_tensor("global_step").item()) <= step + 2
         assert r.get_tensor("dense_1/kernel").abs().sum() > 0
     assert glob.glob(os.path.join(str(tmp_path), "events.out.tfevents.*"))
