@@ -239,10 +239,12 @@ def test_host_feeds_through_pinned_ring_equal_device_feeds(gpu_device):
     x, y = x.numpy() if hasattr(x, "numpy") else x, y.numpy() if hasattr(y, "numpy") else y
     m1, e1 = build()
     m2, e2 = build()
+    m3, e3 = build()
     for i in range(12):      # more steps than the ring is deep
         xb, yb = x[i * 50:(i + 1) * 50], y[i * 50:(i + 1) * 50]
         e1.run([TRAIN_OP], {"x": xb.astype("float64"), "y": yb})                      # host arrays, dtype converted on the way
         e2.run([TRAIN_OP], {"x": torch.as_tensor(xb, dtype=torch.float32).to(gpu_device), "y": torch.as_tensor(yb).to(gpu_device)})
-    assert isinstance(e1._stager, FeedStager) and not hasattr(e2, "_stager")
-    assert torch.equal(m1.store.flat, m2.store.flat)
+        e3.run([TRAIN_OP], {"x": torch.as_tensor(xb, dtype=torch.float32), "y": torch.as_tensor(yb)})   # host tensors
+    assert isinstance(e1._stager, FeedStager) and not hasattr(e2, "_stager") and isinstance(e3._stager, FeedStager)
+    assert torch.equal(m1.store.flat, m2.store.flat) and torch.equal(m3.store.flat, m2.store.flat)
     assert int(m1.store.global_step.item()) == 12
