@@ -4,6 +4,8 @@
 //    /root/reference/example.py:157-164 (Keras mean_squared_error = mean over the last
 //    axis, then reduce_mean over the batch; accuracy = mean(round(p) == round(y)) with
 //    round-half-to-even).
+//  * binary cross-entropy on the same sigmoid outputs (Keras binary_crossentropy: probabilities clipped to
+//    [1e-7, 1 - 1e-7], mean over the last axis), the loss such a head is usually trained with.
 //  * softmax cross-entropy + argmax accuracy for MNIST-shaped classifiers.
 //
 // Every kernel ADDS into a 4-float running-statistics record
@@ -44,6 +46,28 @@ __device__ __forceinline__ void block_add3(float a, float b, float c, float* sta
 // Elementwise over the flat [M*N] range, 16 bytes per lane.  P are probabilities (the dense
 // layer already applied the sigmoid).  G = dLoss/dP * (P (1-P) if through_sigmoid) for
 // Loss = mean_{M,N} (P - Y)^2.  Each element carries weight 1/N into the per-example sums.
+//
+// BCE: Loss = mean_{M,N} -(Y log Pc + (1-Y) log(1-Pc)) with Pc = clip(P, 1e-7, 1 - 1e-7); G = (Pc - Y) / (Pc (1 - Pc))
+// (just Pc - Y through the sigmoid), and zero where the clip is active - the gradient Keras' clip passes on.
+constexpr float BCE_EPS = 1e-7f;
+
+template <bool BCE>
+__device__ __forceinline__ void loss_element(float p, float y, float grad_scale, int through_sigmoid, float& loss,
+                                             float& acc, float& g) {
+    acc += (rintf(p) == rintf(y)) ? 1.f : 0.f;
+    if (BCE) {
+        const float pc = fminf(fmaxf(p, BCE_EPS), 1.0f - BCE_EPS);
+        loss -= y * logf(pc) + (1.0f - y) * logf(1.0f - pc);
+        g = (pc == p) ? (through_sigmoid ? (pc - y) : (pc - y) / (pc * (1.0f - pc))) * grad_scale : 0.0f;
+    } else {
+        const float d = p - y;
+        loss += d * d;
+        g = 2.0f * d * grad_scale;
+        if (through_sigmoid) g *= p * (1.0f - p);
+    }
+}
+
+template <bool BCE>
 __global__ __launch_bounds__(256) void mse_flat_kernel(const float* __restrict__ P, const float* __restrict__ Y,
                                                        float* __restrict__ G, long long total, float inv_n,
                                                        float grad_scale, int through_sigmoid, float* stats) {
@@ -59,26 +83,18 @@ __global__ __launch_bounds__(256) void mse_flat_kernel(const float* __restrict__
         f32x4 g;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float d = p[j] - y[j];
-            loss += d * d;
-            acc += (rintf(p[j]) == rintf(y[j])) ? 1.f : 0.f;
-            float gj = 2.0f * d * grad_scale;
-            if (through_sigmoid) gj *= p[j] * (1.0f - p[j]);
+            float gj;
+            loss_element<BCE>(p[j], y[j], grad_scale, through_sigmoid, loss, acc, gj);
             g[j] = gj;
         }
         cnt += 4.f;
         if (G) G4[i] = g;
     }
     for (long long i = (n4 << 2) + tid; i < total; i += stride) {
-        const float p = P[i], d = p - Y[i];
-        loss += d * d;
-        acc += (rintf(p) == rintf(Y[i])) ? 1.f : 0.f;
+        float gj;
+        loss_element<BCE>(P[i], Y[i], grad_scale, through_sigmoid, loss, acc, gj);
         cnt += 1.f;
-        if (G) {
-            float gj = 2.0f * d * grad_scale;
-            if (through_sigmoid) gj *= p * (1.0f - p);
-            G[i] = gj;
-        }
+        if (G) G[i] = gj;
     }
     if (stats) block_add3(loss * inv_n, acc * inv_n, cnt * inv_n, stats);
 }
@@ -203,8 +219,8 @@ inline int row_grid(int M) {
 
 }  // namespace
 
-DTF_API int dtf_mse_loss(const float* P, const float* Y, float* G, int M, int N, float grad_scale,
-                         int through_sigmoid, float* stats, hipStream_t stream) {
+static int launch_flat_loss(bool bce, const float* P, const float* Y, float* G, int M, int N, float grad_scale,
+                            int through_sigmoid, float* stats, hipStream_t stream) {
     if (M <= 0 || N <= 0) return 0;
     const long long total = (long long)M * N;
     // one workgroup per CU at most: every workgroup ends with three atomic adds on the same three statistics words, and
@@ -212,10 +228,24 @@ DTF_API int dtf_mse_loss(const float* P, const float* Y, float* G, int M, int N,
     long long g = (total / 4 + 255) / 256;
     if (g > 256) g = 256;
     if (g < 1) g = 1;
-    hipLaunchKernelGGL(mse_flat_kernel, dim3((int)g), dim3(256), 0, stream, P, Y, G, total, 1.0f / (float)N,
-                       grad_scale, through_sigmoid, stats);
+    if (bce)
+        hipLaunchKernelGGL(mse_flat_kernel<true>, dim3((int)g), dim3(256), 0, stream, P, Y, G, total, 1.0f / (float)N,
+                           grad_scale, through_sigmoid, stats);
+    else
+        hipLaunchKernelGGL(mse_flat_kernel<false>, dim3((int)g), dim3(256), 0, stream, P, Y, G, total, 1.0f / (float)N,
+                           grad_scale, through_sigmoid, stats);
     DTF_CHECK_LAUNCH();
     return 0;
+}
+
+DTF_API int dtf_mse_loss(const float* P, const float* Y, float* G, int M, int N, float grad_scale,
+                         int through_sigmoid, float* stats, hipStream_t stream) {
+    return launch_flat_loss(false, P, Y, G, M, N, grad_scale, through_sigmoid, stats, stream);
+}
+
+DTF_API int dtf_bce_loss(const float* P, const float* Y, float* G, int M, int N, float grad_scale,
+                         int through_sigmoid, float* stats, hipStream_t stream) {
+    return launch_flat_loss(true, P, Y, G, M, N, grad_scale, through_sigmoid, stats, stream);
 }
 
 DTF_API int dtf_softmax_xent(const float* Z, const long long* sparse_labels, const float* dense_labels, float* G,

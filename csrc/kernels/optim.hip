@@ -11,6 +11,12 @@
 //     v   <- b2 v + (1 - b2) g^2
 //     var <- var - lr_t m / (sqrt(v) + eps)
 // global_step is device-resident (int64) so a captured hipGraph advances by itself.
+//
+// RMSProp and Adagrad are the other two rules a script of this family picks (tf.train.RMSPropOptimizer /
+// tf.train.AdagradOptimizer, Keras 'rmsprop' / 'adagrad'); both keep a running sum of squared gradients per element:
+//     RMSProp   a <- rho a + (1 - rho) g^2     u = lr g / D(a)     mom <- momentum mom + u ; var <- var - mom
+//     Adagrad   a <- a + g^2                   var <- var - lr g / D(a)
+// D(a) = sqrt(a + eps) in TensorFlow's kernels and sqrt(a) + eps in Keras' Python formulas: `eps_inside` selects.
 #include "common.h"
 
 namespace {
@@ -125,6 +131,56 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ var, float
     advance_if_last(adv);
 }
 
+// RULE 0: RMSProp (mom may be null: no momentum slot), RULE 1: Adagrad (rho, momentum, mom unused).
+template <int RULE>
+__global__ __launch_bounds__(256) void accum_rule_kernel(float* __restrict__ var, float* __restrict__ acc,
+                                                         float* __restrict__ mom, const float* __restrict__ g,
+                                                         long long n, float lr, float rho, float momentum, float eps,
+                                                         int eps_inside, float grad_scale, const Advance adv) {
+    const long long n4 = n >> 2;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const float omr = 1.0f - rho;
+    auto one = [&](float gj, float& a, float& mo, float& w) {
+        gj *= grad_scale;
+        a = RULE == 0 ? rho * a + omr * gj * gj : a + gj * gj;
+        const float d = eps_inside ? sqrtf(a + eps) : sqrtf(a) + eps;
+        float u = lr * gj / d;
+        if (RULE == 0 && mom) {
+            mo = momentum * mo + u;
+            u = mo;
+        }
+        w -= u;
+    };
+    f32x4* var4 = reinterpret_cast<f32x4*>(var);
+    f32x4* a4 = reinterpret_cast<f32x4*>(acc);
+    f32x4* mo4 = reinterpret_cast<f32x4*>(mom);
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(g);
+    for (long long i = tid; i < n4; i += stride) {
+        f32x4 gg = g4[i], aa = a4[i], w = var4[i], mm = {0.f, 0.f, 0.f, 0.f};
+        if (RULE == 0 && mom) mm = mo4[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float a = aa[j], mo = mm[j], wj = w[j];
+            one(gg[j], a, mo, wj);
+            aa[j] = a;
+            mm[j] = mo;
+            w[j] = wj;
+        }
+        a4[i] = aa;
+        if (RULE == 0 && mom) mo4[i] = mm;
+        var4[i] = w;
+    }
+    for (long long i = (n4 << 2) + tid; i < n; i += stride) {
+        float a = acc[i], w = var[i], mo = (RULE == 0 && mom) ? mom[i] : 0.f;
+        one(g[i], a, mo, w);
+        acc[i] = a;
+        if (RULE == 0 && mom) mom[i] = mo;
+        var[i] = w;
+    }
+    advance_if_last(adv);
+}
+
 // global_step += 1 and the TF non-slot variables beta1_power / beta2_power *= beta.
 __global__ void step_advance_kernel(long long* step_ptr, float* beta_powers, float b1, float b2) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -173,6 +229,35 @@ DTF_API int dtf_sgd_apply(float* var, float* mom, const float* g, long long n, f
         return -2;
     hipLaunchKernelGGL(sgd_kernel, dim3(flat_grid(n)), dim3(256), 0, stream, var, mom, g, n, lr, momentum,
                        grad_scale, adv);
+    DTF_CHECK_LAUNCH();
+    return 0;
+}
+
+// mom may be null (momentum 0: the slot is not kept)
+DTF_API int dtf_rmsprop_apply(float* var, float* ms, float* mom, const float* g, long long n, float lr, float rho,
+                              float momentum, float eps, int eps_inside, float grad_scale, long long* advance_step,
+                              unsigned int* ticket, hipStream_t stream) {
+    if (n <= 0) return 0;
+    if (advance_step && !ticket) return -3;
+    const Advance adv = {advance_step, nullptr, ticket, 0.f, 0.f};
+    if ((reinterpret_cast<uintptr_t>(var) | reinterpret_cast<uintptr_t>(ms) | reinterpret_cast<uintptr_t>(mom) |
+         reinterpret_cast<uintptr_t>(g)) & 15)
+        return -2;
+    hipLaunchKernelGGL(accum_rule_kernel<0>, dim3(flat_grid(n)), dim3(256), 0, stream, var, ms, mom, g, n, lr, rho,
+                       momentum, eps, eps_inside, grad_scale, adv);
+    DTF_CHECK_LAUNCH();
+    return 0;
+}
+
+DTF_API int dtf_adagrad_apply(float* var, float* acc, const float* g, long long n, float lr, float eps, int eps_inside,
+                              float grad_scale, long long* advance_step, unsigned int* ticket, hipStream_t stream) {
+    if (n <= 0) return 0;
+    if (advance_step && !ticket) return -3;
+    const Advance adv = {advance_step, nullptr, ticket, 0.f, 0.f};
+    if ((reinterpret_cast<uintptr_t>(var) | reinterpret_cast<uintptr_t>(acc) | reinterpret_cast<uintptr_t>(g)) & 15)
+        return -2;
+    hipLaunchKernelGGL(accum_rule_kernel<1>, dim3(flat_grid(n)), dim3(256), 0, stream, var, acc, nullptr, g, n, lr,
+                       0.f, 0.f, eps, eps_inside, grad_scale, adv);
     DTF_CHECK_LAUNCH();
     return 0;
 }

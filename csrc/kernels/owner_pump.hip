@@ -41,6 +41,11 @@
 extern "C" int dtf_adam_apply(float* var, float* m, float* v, const float* g, long long n, float lr, float b1, float b2,
                               float eps, float grad_scale, const long long* step_ptr, long long* advance_step,
                               float* beta_powers, unsigned int* ticket, hipStream_t stream);
+extern "C" int dtf_rmsprop_apply(float* var, float* ms, float* mom, const float* g, long long n, float lr, float rho,
+                                 float momentum, float eps, int eps_inside, float grad_scale, long long* advance_step,
+                                 unsigned int* ticket, hipStream_t stream);
+extern "C" int dtf_adagrad_apply(float* var, float* acc, const float* g, long long n, float lr, float eps, int eps_inside,
+                                 float grad_scale, long long* advance_step, unsigned int* ticket, hipStream_t stream);
 extern "C" int dtf_sgd_apply(float* var, float* mom, const float* g, long long n, float lr, float momentum,
                              float grad_scale, long long* advance_step, unsigned int* ticket, hipStream_t stream);
 
@@ -72,7 +77,7 @@ static_assert(offsetof(Ctl, lane) == 128, "control block layout is shared with t
 
 struct Config {
     int on_gpu, owner, workers, depth;
-    int optimizer;                              // 0 Adam, 1 SGD (momentum slot optional)
+    int optimizer;                              // 0 Adam, 1 SGD (momentum slot optional), 2 RMSProp, 3 Adagrad
     int pad;
     long long n;                                // elements of this owner's shard
     long long slot_stride;                      // elements between inbox slots
@@ -220,7 +225,7 @@ void cpu_apply(const Config& c, const float* g) {
             c.beta_powers[0] *= c.b1;
             c.beta_powers[1] *= c.b2;
         }
-    } else {
+    } else if (c.optimizer == 1) {
         for (long long i = 0; i < n; ++i) {
             float gi = g[i];
             if (c.m && c.momentum > 0.0f) {
@@ -228,6 +233,21 @@ void cpu_apply(const Config& c, const float* g) {
                 c.m[i] = gi;
             }
             c.var[i] -= c.lr * gi;
+        }
+    } else {
+        // RMSProp (2: m = mean square, v = momentum accumulator or null, b1 = rho) and Adagrad (3: m = accumulator);
+        // b2 != 0: epsilon inside the root (TensorFlow's kernels), else outside (Keras' formulas) - as optim.hip
+        const bool inside = c.b2 != 0.0f;
+        for (long long i = 0; i < n; ++i) {
+            const float gi = g[i];
+            const float a = c.optimizer == 2 ? c.b1 * c.m[i] + (1.0f - c.b1) * gi * gi : c.m[i] + gi * gi;
+            c.m[i] = a;
+            float u = c.lr * gi / (inside ? std::sqrt(a + c.eps) : std::sqrt(a) + c.eps);
+            if (c.optimizer == 2 && c.v && c.momentum > 0.0f) {
+                u = c.momentum * c.v[i] + u;
+                c.v[i] = u;
+            }
+            c.var[i] -= u;
         }
     }
     *c.step += 1;
@@ -239,8 +259,13 @@ int gpu_apply(Pump* p, const float* g) {
     if (c.optimizer == 0)
         return dtf_adam_apply(c.var, c.m, c.v, g, c.n, c.lr, c.b1, c.b2, c.eps, 1.0f, c.step, c.step, c.beta_powers,
                               c.ticket, p->stream);
-    return dtf_sgd_apply(c.var, c.momentum > 0.0f ? c.m : nullptr, g, c.n, c.lr, c.momentum, 1.0f, c.step, c.ticket,
-                         p->stream);
+    if (c.optimizer == 1)
+        return dtf_sgd_apply(c.var, c.momentum > 0.0f ? c.m : nullptr, g, c.n, c.lr, c.momentum, 1.0f, c.step, c.ticket,
+                             p->stream);
+    if (c.optimizer == 2)
+        return dtf_rmsprop_apply(c.var, c.m, c.momentum > 0.0f ? c.v : nullptr, g, c.n, c.lr, c.b1, c.momentum, c.eps,
+                                 c.b2 != 0.0f ? 1 : 0, 1.0f, c.step, c.ticket, p->stream);
+    return dtf_adagrad_apply(c.var, c.m, g, c.n, c.lr, c.eps, c.b2 != 0.0f ? 1 : 0, 1.0f, c.step, c.ticket, p->stream);
 }
 
 void pump_loop(Pump* p, int device) {

@@ -344,6 +344,7 @@ def _eval_generic(node, env: Dict[Tensor, torch.Tensor], engine: "GraphEngine", 
     elif op == "reduce_sum":
         out = ins[0].sum() if node.attrs["axis"] is None else ins[0].sum(dim=node.attrs["axis"])
     elif op == "keras_mse": out = ((ins[1] - ins[0]) ** 2).mean(dim=-1)
+    elif op == "keras_bce": out = _losses.binary_crossentropy(ins[0], ins[1])
     elif op == "softmax_xent":
         out = -(ins[0] * torch.log_softmax(ins[1], dim=1)).sum(dim=1)
     elif op == "sparse_softmax_xent":
@@ -416,7 +417,7 @@ class GraphEngine(ModelEngine):
         order = GraphModel._topological(self.loss_node)
         label_set = []
         for n in order:
-            if n.op in ("keras_mse", "softmax_xent", "sparse_softmax_xent") and _match(n.inputs[0], "Placeholder"):
+            if n.op in ("keras_mse", "keras_bce", "softmax_xent", "sparse_softmax_xent") and _match(n.inputs[0], "Placeholder"):
                 label_set.append(n.inputs[0])
             elif n.op == "sub":
                 label_set += [i for i in n.inputs if _match(i, "Placeholder")]
@@ -426,7 +427,7 @@ class GraphEngine(ModelEngine):
                 if isinstance(i, Tensor):
                     consumers.setdefault(id(i), []).append(n)
         labels = [p for p in dict.fromkeys(label_set)
-                  if all(c.op in ("keras_mse", "softmax_xent", "sparse_softmax_xent", "sub") for c in consumers.get(id(p), []))]
+                  if all(c.op in ("keras_mse", "keras_bce", "softmax_xent", "sparse_softmax_xent", "sub") for c in consumers.get(id(p), []))]
         inputs = [n for n in order if n.op == "Placeholder" and n not in labels and n is not self.graph.learning_phase]
         if not inputs or not labels:
             raise NotImplementedError("the loss must depend on at least one input placeholder and one label placeholder")
@@ -435,7 +436,7 @@ class GraphEngine(ModelEngine):
         # the output a metric or a fetch of predictions refers to: the non-label operand of the first loss op
         self.preds = None
         for n in order:
-            if n.op in ("keras_mse", "softmax_xent", "sparse_softmax_xent"):
+            if n.op in ("keras_mse", "keras_bce", "softmax_xent", "sparse_softmax_xent"):
                 self.preds = n.inputs[1]
                 break
         acc = None
@@ -561,6 +562,9 @@ class GraphEngine(ModelEngine):
         if _match(node, "reduce_mean") and _match(node.inputs[0], "keras_mse"):
             m = node.inputs[0]
             return "mean_squared_error", m.inputs[0], m.inputs[1]
+        if _match(node, "reduce_mean") and _match(node.inputs[0], "keras_bce"):
+            m = node.inputs[0]
+            return "binary_crossentropy", m.inputs[0], m.inputs[1]
         if _match(node, "reduce_mean") and _match(node.inputs[0], "softmax_xent"):
             m = node.inputs[0]
             return "categorical_crossentropy", m.inputs[0], m.inputs[1]
@@ -573,7 +577,7 @@ class GraphEngine(ModelEngine):
             preds, labels = (b, a) if _match(a, "Placeholder") else (a, b)      # the fed operand is the label
             return "mean_squared_error", labels, preds
         raise NotImplementedError(
-            "minimize() supports reduce_mean of keras.losses.mean_squared_error, tf.square(a - b), "
+            "minimize() supports reduce_mean of keras.losses.mean_squared_error / binary_crossentropy, tf.square(a - b), "
             "tf.nn.softmax_cross_entropy_with_logits or tf.nn.sparse_softmax_cross_entropy_with_logits")
 
     def _match_accuracy(self, node) -> Optional[str]:
@@ -760,6 +764,19 @@ class MomentumOptimizer(_GraphOptimizer):
         super().__init__(_optimizers.SGD(lr=learning_rate, momentum=momentum))
 
 
+class RMSPropOptimizer(_GraphOptimizer):
+    def __init__(self, learning_rate, decay=0.9, momentum=0.0, epsilon=1e-10, use_locking=False, centered=False,
+                 name="RMSProp"):
+        if centered:
+            raise NotImplementedError("RMSPropOptimizer(centered=True) is not supported")
+        super().__init__(_optimizers.RMSProp(lr=learning_rate, decay=decay, momentum=momentum, epsilon=epsilon))
+
+
+class AdagradOptimizer(_GraphOptimizer):
+    def __init__(self, learning_rate, initial_accumulator_value=0.1, use_locking=False, name="Adagrad"):
+        super().__init__(_optimizers.Adagrad(lr=learning_rate, initial_accumulator_value=initial_accumulator_value))
+
+
 class SyncReplicasOptimizer(_GraphOptimizer):
     """``tf.train.SyncReplicasOptimizer(opt, replicas_to_aggregate=N)``: gradients of all workers are averaged
     and applied once per global step (reduce-scatter / sharded apply / all-gather)."""
@@ -794,6 +811,7 @@ summary = types.SimpleNamespace(scalar=_summary.scalar, merge_all=_summary.merge
 
 train = types.SimpleNamespace(
     AdamOptimizer=AdamOptimizer, GradientDescentOptimizer=GradientDescentOptimizer, MomentumOptimizer=MomentumOptimizer,
+    RMSPropOptimizer=RMSPropOptimizer, AdagradOptimizer=AdagradOptimizer,
     SyncReplicasOptimizer=SyncReplicasOptimizer, ClusterSpec=_cluster.ClusterSpec, Server=_cluster.Server,
     replica_device_setter=_cluster.replica_device_setter, StopAtStepHook=_session.StopAtStepHook,
     StepCounterHook=_session.StepCounterHook, SummarySaverHook=_session.SummarySaverHook,
@@ -866,13 +884,21 @@ def _keras_mse(y_true, y_pred):
     return _losses.mean_squared_error(y_true, y_pred)
 
 
+def _keras_bce(y_true, y_pred):
+    if isinstance(y_true, Tensor) or isinstance(y_pred, Tensor):
+        return Tensor("keras_bce", [y_true, y_pred], name="binary_crossentropy")
+    return _losses.binary_crossentropy(y_true, y_pred)
+
+
 keras = types.SimpleNamespace(
     layers=types.SimpleNamespace(Dense=_Dense, Dropout=_Dropout, Activation=_Activation, Flatten=_Flatten,
                                  Conv2D=_Conv2D, MaxPooling2D=_MaxPooling2D),
     models=types.SimpleNamespace(Sequential=_Sequential),
     backend=_KerasBackend,
-    losses=types.SimpleNamespace(mean_squared_error=_keras_mse),
+    losses=types.SimpleNamespace(mean_squared_error=_keras_mse, binary_crossentropy=_keras_bce),
     callbacks=types.SimpleNamespace(TensorBoard=_callbacks.TensorBoard, Callback=_callbacks.Callback,
                                     History=_callbacks.History),
-    optimizers=types.SimpleNamespace(Adam=_optimizers.Adam, SGD=_optimizers.SGD),
+    optimizers=types.SimpleNamespace(Adam=_optimizers.Adam, SGD=_optimizers.SGD,
+                                     RMSprop=lambda **kw: _optimizers.RMSProp(keras=True, **kw),
+                                     Adagrad=lambda **kw: _optimizers.Adagrad(keras=True, **kw)),
 )

@@ -224,7 +224,8 @@ def model_nodes(model, worker_device: str = "", variable_device=None, loss_name:
         out_shape = getattr(model, "output_shape", None)
         nodes.append(Node(labels_name, "Placeholder", device=worker_device, dtype=DT_FLOAT,
                           shape=[None] + list(out_shape or [])))
-        nodes.append(Node("loss/%s" % loss_name, {"mean_squared_error": "SquaredDifference"}.get(
+        nodes.append(Node("loss/%s" % loss_name, {"mean_squared_error": "SquaredDifference",
+                                                  "binary_crossentropy": "SigmoidCrossEntropyWithLogits"}.get(
             loss_name, "SoftmaxCrossEntropyWithLogits"), [cur, labels_name], device=worker_device))
         nodes.append(Node("loss/Mean", "Mean", ["loss/%s" % loss_name], device=worker_device))
         gs_dev = vdev("global_step")
@@ -233,7 +234,8 @@ def model_nodes(model, worker_device: str = "", variable_device=None, loss_name:
         opt = optimizer_name or "Adam"
         updates = []
         for v in var_names:
-            slots = {"Adam": ["Adam", "Adam_1"], "SGD": []}.get(opt, [])
+            slots = {"Adam": ["Adam", "Adam_1"], "SGD": [], "RMSProp": ["RMSProp", "RMSProp_1"],
+                     "Adagrad": ["Adagrad"]}.get(opt, [])
             for s in slots:
                 nodes.append(Node("%s/%s" % (v, s), "VariableV2", device=vdev(v), dtype=DT_FLOAT))
             up = "%s/update_%s/Apply%s" % (opt, v, {"SGD": "GradientDescent"}.get(opt, opt))

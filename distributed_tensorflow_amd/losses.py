@@ -26,11 +26,8 @@ class Loss:
         raise NotImplementedError
 
 
-class MeanSquaredError(Loss):
-    """Keras ``mean_squared_error``: mean over the last axis, then over the batch
-    (/root/reference/example.py:163)."""
-
-    name = "mean_squared_error"
+class _ElementwiseLoss(Loss):
+    """Losses over probabilities, element by element: behind a sigmoid head the kernel emits dL/dz directly."""
 
     def __init__(self):
         self.through_sigmoid = False
@@ -40,8 +37,25 @@ class MeanSquaredError(Loss):
             and getattr(head, "fused_keep", 1.0) >= 1.0
         return self.through_sigmoid
 
+
+class MeanSquaredError(_ElementwiseLoss):
+    """Keras ``mean_squared_error``: mean over the last axis, then over the batch
+    (/root/reference/example.py:163)."""
+
+    name = "mean_squared_error"
+
     def __call__(self, y_pred, y_true, grad_out, stats, grad_scale=None):
         return F.mse_loss(y_pred, y_true, grad_out, grad_scale, self.through_sigmoid, stats)
+
+
+class BinaryCrossentropy(_ElementwiseLoss):
+    """Keras ``binary_crossentropy`` on sigmoid outputs (probabilities clipped to ``[1e-7, 1 - 1e-7]``, mean over the
+    last axis, then over the batch); with a sigmoid head the gradient handed back is dL/dz = p - y."""
+
+    name = "binary_crossentropy"
+
+    def __call__(self, y_pred, y_true, grad_out, stats, grad_scale=None):
+        return F.bce_loss(y_pred, y_true, grad_out, grad_scale, self.through_sigmoid, stats)
 
 
 class CategoricalCrossentropy(Loss):
@@ -79,6 +93,7 @@ class SparseCategoricalCrossentropy(Loss):
 _REGISTRY = {
     "mean_squared_error": MeanSquaredError,
     "mse": MeanSquaredError,
+    "binary_crossentropy": BinaryCrossentropy,
     "categorical_crossentropy": CategoricalCrossentropy,
     "softmax_cross_entropy": CategoricalCrossentropy,
     "sparse_categorical_crossentropy": SparseCategoricalCrossentropy,
@@ -94,6 +109,12 @@ def get(spec) -> Loss:
     if spec in _REGISTRY:
         return _REGISTRY[spec]()
     raise ValueError("unknown loss %r (have: %s)" % (spec, ", ".join(sorted(_REGISTRY))))
+
+
+def binary_crossentropy(y_true: torch.Tensor, y_pred: torch.Tensor) -> torch.Tensor:
+    """Functional Keras form: per-example binary cross-entropy over the last axis."""
+    pc = y_pred.clamp(F.BCE_EPS, 1.0 - F.BCE_EPS)
+    return (-(y_true * pc.log() + (1.0 - y_true) * (1.0 - pc).log())).mean(dim=-1)
 
 
 def mean_squared_error(y_true: torch.Tensor, y_pred: torch.Tensor) -> torch.Tensor:

@@ -172,13 +172,15 @@ class GraphModel(Sequential):
             else:
                 raise KeyError("variable %s has no value in this model" % node.name)
         elif op == "reduce_mean" and node.attrs.get("axis") is None and _is_node(node.inputs[0]) \
-                and node.inputs[0].op in ("keras_mse", "softmax_xent", "sparse_softmax_xent"):
+                and node.inputs[0].op in ("keras_mse", "keras_bce", "softmax_xent", "sparse_softmax_xent"):
             # the fused loss kernels: value and gradient from one launch
             inner = node.inputs[0]
             y = self._eval(inner.inputs[0], env, training)
             p = self._eval(inner.inputs[1], env, training)
             if inner.op == "keras_mse":
                 out = A.mean_squared_error(p, y.to(torch.float32))
+            elif inner.op == "keras_bce":
+                out = A.binary_crossentropy(p, y.to(torch.float32))
             else:
                 out = A.softmax_cross_entropy(p, y if inner.op == "sparse_softmax_xent" and y.dtype == torch.int64
                                               else (y.long() if inner.op == "sparse_softmax_xent" else y))
@@ -223,6 +225,9 @@ class GraphModel(Sequential):
                 out = ins[0].sum() if ax is None else ins[0].sum(dim=ax)
             elif op == "keras_mse":
                 out = ((ins[1] - ins[0]) ** 2).mean(dim=-1)
+            elif op == "keras_bce":
+                pc = ins[1].clamp(F.BCE_EPS, 1.0 - F.BCE_EPS)
+                out = (-(ins[0] * pc.log() + (1.0 - ins[0]) * (1.0 - pc).log())).mean(dim=-1)
             elif op == "softmax_xent":
                 out = -(ins[0] * torch.log_softmax(ins[1], dim=1)).sum(dim=1)
             elif op == "sparse_softmax_xent":

@@ -65,10 +65,13 @@ def kernels():
         "dtf_conv_wgrad_splits": [c_i, c_i, c_i],
         "dtf_dense_bwd_dw": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p],
         "dtf_mse_loss": [c_p, c_p, c_p, c_i, c_i, c_f, c_i, c_p, c_p],
+        "dtf_bce_loss": [c_p, c_p, c_p, c_i, c_i, c_f, c_i, c_p, c_p],
         "dtf_softmax_xent": [c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_p, c_p],
         "dtf_categorical_accuracy": [c_p, c_p, c_i, c_i, c_p, c_p],
         "dtf_adam_apply": [c_p, c_p, c_p, c_p, c_ll, c_f, c_f, c_f, c_f, c_f, c_p, c_p, c_p, c_p, c_p],
         "dtf_sgd_apply": [c_p, c_p, c_p, c_ll, c_f, c_f, c_f, c_p, c_p, c_p],
+        "dtf_rmsprop_apply": [c_p, c_p, c_p, c_p, c_ll, c_f, c_f, c_f, c_f, c_i, c_f, c_p, c_p, c_p],
+        "dtf_adagrad_apply": [c_p, c_p, c_p, c_ll, c_f, c_f, c_i, c_f, c_p, c_p, c_p],
         "dtf_step_advance": [c_p, c_p, c_f, c_f, c_p],
         "dtf_act_grad": [c_p, c_p, c_p, c_ll, c_i, c_f, c_p],
         "dtf_dropout": [c_p, c_p, c_ll, c_f, c_u32, c_p, c_p],

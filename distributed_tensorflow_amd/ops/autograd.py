@@ -158,6 +158,30 @@ def mean_squared_error(pred, target):
     return _MseFn.apply(pred, target)
 
 
+class _BceFn(torch.autograd.Function):
+    """Keras ``binary_crossentropy`` averaged over the batch (probabilities clipped to ``[1e-7, 1 - 1e-7]``)."""
+
+    @staticmethod
+    def forward(ctx, p, y):
+        p, y = _c(p), _c(y)
+        p2, y2 = p.reshape(p.shape[0], -1), y.reshape(y.shape[0], -1)
+        g = torch.empty_like(p2)
+        st = F.new_stats(p.device)
+        F.bce_loss(p2, y2, g, None, False, st)
+        ctx.save_for_backward(g)
+        ctx.shape = p.shape
+        return st[0] / p2.shape[0]
+
+    @staticmethod
+    def backward(ctx, dl):
+        (g,) = ctx.saved_tensors
+        return (g * dl).reshape(ctx.shape), None
+
+
+def binary_crossentropy(pred, target):
+    return _BceFn.apply(pred, target)
+
+
 class _Conv2dFn(torch.autograd.Function):
     """NHWC convolution with a TensorFlow filter ``[KH, KW, C, N]``: patch matrix x filter matrix on the dense GEMM
     kernels (forward, weight gradient, data gradient + col2im), bias and activation fused."""

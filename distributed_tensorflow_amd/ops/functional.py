@@ -303,6 +303,33 @@ def mse_loss(p, y, grad_out=None, grad_scale=None, through_sigmoid=False, stats=
     return grad_out
 
 
+BCE_EPS = 1e-7
+
+
+def bce_loss(p, y, grad_out=None, grad_scale=None, through_sigmoid=False, stats=None):
+    """Keras ``binary_crossentropy`` on probabilities ``p`` (clipped to ``[1e-7, 1 - 1e-7]``, mean over the last axis)
+    + rounded-equality accuracy, gradient fused: ``grad_out`` receives d(mean loss)/dp - or, ``through_sigmoid``, the
+    gradient w.r.t. the logits, ``p - y`` - and zero where the clip is active."""
+    M, N = p.shape
+    if grad_scale is None:
+        grad_scale = 1.0 / (M * N)
+    if p.is_cuda:
+        nv.require_f32_contig(p, y, grad_out, stats)
+        rc = nv.kernels().dtf_bce_loss(nv.ptr(p), nv.ptr(y), nv.ptr(grad_out), M, N, float(grad_scale),
+                                       int(bool(through_sigmoid)), nv.ptr(stats), nv.stream_ptr())
+        nv.check(rc, "dtf_bce_loss")
+        return grad_out
+    pc = p.clamp(BCE_EPS, 1.0 - BCE_EPS)
+    if grad_out is not None:
+        g = (pc - y) if through_sigmoid else (pc - y) / (pc * (1.0 - pc))
+        grad_out.copy_(torch.where(pc == p, g * grad_scale, torch.zeros_like(g)))
+    if stats is not None:
+        stats[0] += (-(y * pc.log() + (1.0 - y) * (1.0 - pc).log())).mean(dim=1).sum()
+        stats[1] += (torch.round(p) == torch.round(y)).to(torch.float32).mean(dim=1).sum()
+        stats[2] += float(M)
+    return grad_out
+
+
 def softmax_xent(z, labels, grad_out=None, grad_scale=None, stats=None):
     """Softmax cross-entropy on logits ``z`` [M,C] + argmax accuracy, gradient fused.
 
@@ -408,6 +435,53 @@ def sgd_apply(var, grad, lr, momentum_buf=None, momentum=0.0, grad_scale=1.0, ad
         momentum_buf.mul_(momentum).add_(g)
         g = momentum_buf
     var.sub_(lr * g)
+    if advance is not None:
+        step_advance(advance)
+    return var
+
+
+def rmsprop_apply(var, ms, grad, lr, rho=0.9, momentum_buf=None, momentum=0.0, eps=1e-10, eps_inside=True, grad_scale=1.0,
+                  advance=None):
+    """RMSProp on flat fp32 ranges: ``ms <- rho ms + (1-rho) g^2``, ``u = lr g / D(ms)``, with a momentum
+    accumulator ``mom <- momentum mom + u; var -= mom``, else ``var -= u``.  ``D(a) = sqrt(a + eps)`` (TensorFlow's
+    ApplyRMSProp) or ``sqrt(a) + eps`` (Keras) by ``eps_inside``."""
+    n = var.numel()
+    assert ms.numel() == n and grad.numel() == n and (momentum_buf is None or momentum_buf.numel() == n)
+    if var.is_cuda:
+        nv.require_f32_contig(var, ms, grad, momentum_buf)
+        rc = nv.kernels().dtf_rmsprop_apply(nv.ptr(var), nv.ptr(ms), nv.ptr(momentum_buf), nv.ptr(grad), n, float(lr),
+                                            float(rho), float(momentum), float(eps), int(bool(eps_inside)), float(grad_scale),
+                                            nv.ptr(advance), nv.ptr(_ticket(var.device)) if advance is not None else 0,
+                                            nv.stream_ptr())
+        nv.check(rc, "dtf_rmsprop_apply")
+        return var
+    g = grad * grad_scale
+    ms.mul_(rho).addcmul_(g, g, value=1.0 - rho)
+    u = lr * g / ((ms + eps).sqrt() if eps_inside else ms.sqrt() + eps)
+    if momentum_buf is not None:
+        momentum_buf.mul_(momentum).add_(u)
+        u = momentum_buf
+    var.sub_(u)
+    if advance is not None:
+        step_advance(advance)
+    return var
+
+
+def adagrad_apply(var, acc, grad, lr, eps=0.0, eps_inside=True, grad_scale=1.0, advance=None):
+    """Adagrad on flat fp32 ranges: ``acc += g^2; var -= lr g / D(acc)`` (``D`` as in ``rmsprop_apply``; TensorFlow's
+    ApplyAdagrad has no epsilon and starts ``acc`` at 0.1)."""
+    n = var.numel()
+    assert acc.numel() == n and grad.numel() == n
+    if var.is_cuda:
+        nv.require_f32_contig(var, acc, grad)
+        rc = nv.kernels().dtf_adagrad_apply(nv.ptr(var), nv.ptr(acc), nv.ptr(grad), n, float(lr), float(eps),
+                                            int(bool(eps_inside)), float(grad_scale), nv.ptr(advance),
+                                            nv.ptr(_ticket(var.device)) if advance is not None else 0, nv.stream_ptr())
+        nv.check(rc, "dtf_adagrad_apply")
+        return var
+    g = grad * grad_scale
+    acc.addcmul_(g, g)
+    var.sub_(lr * g / ((acc + eps).sqrt() if eps_inside else acc.sqrt() + eps))
     if advance is not None:
         step_advance(advance)
     return var

@@ -5,6 +5,11 @@ Keras ``'adam'`` string (/root/reference/example2.py:165): lr 1e-3, beta1 .9, be
 eps 1e-8, TensorFlow epsilon placement.  ``apply`` takes a ``[begin, end)`` range so the
 same fused kernel serves "all variables" (single process), "my shard" (sync replicas
 after a reduce-scatter) and "this owner's shard" (parameter-server owner).
+
+``SGD`` (with momentum), ``RMSProp`` and ``Adagrad`` are the other rules a script written against
+``tf.train.*Optimizer`` or Keras' optimizer strings may name; each comes in the TensorFlow form (slot names, initial
+slot values and epsilon placement of TF's Apply* kernels, so checkpoints carry the names TF expects) and, through
+``get('rmsprop')`` / ``get('adagrad')``, in the form of Keras 2.0.8's Python formulas.
 """
 from __future__ import annotations
 
@@ -18,6 +23,23 @@ class Optimizer:
     #: slot buffer name -> suffix used in TF checkpoints ("<var>/<suffix>")
     slot_checkpoint_names: Dict[str, str] = {}
     name = "optimizer"
+
+    @property
+    def slot_order(self):
+        """Slot buffers in the order a variable owner lays them out behind its variables."""
+        return list(self.slot_checkpoint_names)
+
+    def slot_initial(self, slot_name: str) -> float:
+        """Value a fresh slot buffer starts from."""
+        return 0.0
+
+    def describe(self) -> dict:
+        """``{"name", "args"}`` from which ``from_description`` rebuilds this optimizer in another process."""
+        raise NotImplementedError
+
+    def pump_parameters(self):
+        """``(code, lr, b1, b2, eps, momentum)`` of the native owner service (`csrc/kernels/owner_pump.hip`)."""
+        raise NotImplementedError
 
     def apply(self, store: VariableStore, begin: int = 0, end: Optional[int] = None, grad_scale: float = 1.0,
               grad=None, step=None):
@@ -48,6 +70,12 @@ class Adam(Optimizer):
         self.beta1 = float(beta1 if beta1 is not None else beta_1)
         self.beta2 = float(beta2 if beta2 is not None else beta_2)
         self.epsilon = float(epsilon)
+
+    def describe(self):
+        return {"name": "Adam", "args": {"lr": self.lr, "beta_1": self.beta1, "beta_2": self.beta2, "epsilon": self.epsilon}}
+
+    def pump_parameters(self):
+        return 0, self.lr, self.beta1, self.beta2, self.epsilon, 0.0
 
     def create_slots(self, store):
         store.slot("m")
@@ -82,6 +110,16 @@ class SGD(Optimizer):
         self.lr = float(learning_rate if learning_rate is not None else lr)
         self.momentum = float(momentum)
 
+    @property
+    def slot_order(self):
+        return ["momentum"] if self.momentum > 0.0 else []
+
+    def describe(self):
+        return {"name": "SGD", "args": {"lr": self.lr, "momentum": self.momentum}}
+
+    def pump_parameters(self):
+        return 1, self.lr, 0.0, 0.0, 0.0, self.momentum
+
     def create_slots(self, store):
         if self.momentum > 0.0:
             store.slot("momentum")
@@ -97,6 +135,100 @@ class SGD(Optimizer):
         F.sgd_apply(store.flat, store.flat_grad, self.lr, mom, self.momentum, grad_scale, advance=store.global_step)
 
 
+class RMSProp(Optimizer):
+    """``tf.train.RMSPropOptimizer(learning_rate, decay=0.9, momentum=0.0, epsilon=1e-10)``: TF's ApplyRMSProp
+    (``var -= lr g / sqrt(ms + eps)``, ``ms`` starting at ONE, slots ``<var>/RMSProp`` and - always present in TF's
+    checkpoints, kept here only with ``momentum > 0`` - ``<var>/RMSProp_1``).  ``keras=True``: Keras 2.0.8's
+    ``RMSprop(lr=0.001, rho=0.9, epsilon=1e-8)``, accumulator from zero and epsilon outside the root."""
+
+    slot_checkpoint_names = {"rms": "RMSProp", "momentum": "RMSProp_1"}
+    name = "RMSProp"
+
+    def __init__(self, lr: float = 0.001, decay: float = 0.9, momentum: float = 0.0, epsilon: Optional[float] = None,
+                 learning_rate: Optional[float] = None, rho: Optional[float] = None, keras: bool = False):
+        self.lr = float(learning_rate if learning_rate is not None else lr)
+        self.rho = float(rho if rho is not None else decay)
+        self.momentum = float(momentum)
+        self.keras = bool(keras)
+        self.epsilon = float(epsilon if epsilon is not None else (1e-8 if keras else 1e-10))
+
+    @property
+    def slot_order(self):
+        return ["rms", "momentum"] if self.momentum > 0.0 else ["rms"]
+
+    def slot_initial(self, slot_name):
+        return 1.0 if slot_name == "rms" and not self.keras else 0.0
+
+    def describe(self):
+        return {"name": "RMSProp", "args": {"lr": self.lr, "decay": self.rho, "momentum": self.momentum,
+                                            "epsilon": self.epsilon, "keras": self.keras}}
+
+    def pump_parameters(self):
+        # b1 carries rho, b2 the epsilon placement
+        return 2, self.lr, self.rho, 0.0 if self.keras else 1.0, self.epsilon, self.momentum
+
+    def create_slots(self, store):
+        for name in self.slot_order:
+            store.slot(name, self.slot_initial(name))
+
+    def apply(self, store, begin=0, end=None, grad_scale=1.0, grad=None, step=None):
+        end = store.flat_len if end is None else end
+        g = store.flat_grad if grad is None else grad
+        mom = store.slot("momentum")[begin:end] if self.momentum > 0.0 else None
+        F.rmsprop_apply(store.flat[begin:end], store.slot("rms", self.slot_initial("rms"))[begin:end], g[begin:end], self.lr,
+                        self.rho, mom, self.momentum, self.epsilon, not self.keras, grad_scale)
+
+    def apply_and_finish(self, store, grad_scale=1.0):
+        mom = store.slot("momentum") if self.momentum > 0.0 else None
+        F.rmsprop_apply(store.flat, store.slot("rms", self.slot_initial("rms")), store.flat_grad, self.lr, self.rho, mom,
+                        self.momentum, self.epsilon, not self.keras, grad_scale, advance=store.global_step)
+
+
+class Adagrad(Optimizer):
+    """``tf.train.AdagradOptimizer(learning_rate, initial_accumulator_value=0.1)``: TF's ApplyAdagrad
+    (``acc += g^2; var -= lr g / sqrt(acc)``, slot ``<var>/Adagrad``).  ``keras=True``: Keras 2.0.8's
+    ``Adagrad(lr=0.01, epsilon=1e-8)``, accumulator from zero and ``sqrt(acc) + epsilon``."""
+
+    slot_checkpoint_names = {"accumulator": "Adagrad"}
+    name = "Adagrad"
+
+    def __init__(self, lr: float = 0.01, initial_accumulator_value: Optional[float] = None, epsilon: Optional[float] = None,
+                 learning_rate: Optional[float] = None, keras: bool = False):
+        self.lr = float(learning_rate if learning_rate is not None else lr)
+        self.keras = bool(keras)
+        self.initial = float(initial_accumulator_value if initial_accumulator_value is not None else (0.0 if keras else 0.1))
+        self.epsilon = float(epsilon if epsilon is not None else (1e-8 if keras else 0.0))
+
+    def slot_initial(self, slot_name):
+        return self.initial
+
+    def describe(self):
+        return {"name": "Adagrad", "args": {"lr": self.lr, "initial_accumulator_value": self.initial,
+                                            "epsilon": self.epsilon, "keras": self.keras}}
+
+    def pump_parameters(self):
+        return 3, self.lr, 0.0, 0.0 if self.keras else 1.0, self.epsilon, 0.0
+
+    def create_slots(self, store):
+        store.slot("accumulator", self.initial)
+
+    def apply(self, store, begin=0, end=None, grad_scale=1.0, grad=None, step=None):
+        end = store.flat_len if end is None else end
+        g = store.flat_grad if grad is None else grad
+        F.adagrad_apply(store.flat[begin:end], store.slot("accumulator", self.initial)[begin:end], g[begin:end], self.lr,
+                        self.epsilon, not self.keras, grad_scale)
+
+    def apply_and_finish(self, store, grad_scale=1.0):
+        F.adagrad_apply(store.flat, store.slot("accumulator", self.initial), store.flat_grad, self.lr, self.epsilon,
+                        not self.keras, grad_scale, advance=store.global_step)
+
+
+def from_description(desc: dict) -> Optimizer:
+    """Inverse of ``Optimizer.describe`` (how a parameter-server task learns which rule its shard is updated by)."""
+    classes = {"Adam": Adam, "SGD": SGD, "RMSProp": RMSProp, "Adagrad": Adagrad}
+    return classes[desc["name"]](**desc["args"])
+
+
 def initial_beta_powers(optimizer, device):
     """Initial value of the ``[beta1_power, beta2_power]`` pair for ``optimizer`` (ones for optimizers without them)."""
     import torch
@@ -110,11 +242,16 @@ AdamOptimizer = Adam
 GradientDescentOptimizer = SGD
 
 
+RMSPropOptimizer = RMSProp
+AdagradOptimizer = Adagrad
+
+
 def MomentumOptimizer(learning_rate, momentum):
     return SGD(lr=learning_rate, momentum=momentum)
 
 
-_REGISTRY = {"adam": Adam, "sgd": SGD}
+# the Keras strings build the Keras forms
+_REGISTRY = {"adam": Adam, "sgd": SGD, "rmsprop": lambda: RMSProp(keras=True), "adagrad": lambda: Adagrad(keras=True)}
 
 
 def get(spec) -> Optimizer:
@@ -126,4 +263,4 @@ def get(spec) -> Optimizer:
         return spec
     if isinstance(spec, str) and spec.lower() in _REGISTRY:
         return _REGISTRY[spec.lower()]()
-    raise ValueError("unknown optimizer %r (have: adam, sgd)" % (spec,))
+    raise ValueError("unknown optimizer %r (have: %s)" % (spec, ", ".join(sorted(_REGISTRY))))

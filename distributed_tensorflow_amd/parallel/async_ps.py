@@ -311,18 +311,23 @@ class ParameterServerService:
             self.beta_powers = svc.beta_powers
             self._svc = svc
 
-        def slot(self, name):
+        def slot(self, name, initial=None):
             s = self._svc.slots
             if name not in s:
                 svc = self._svc
+                first = float(svc.opt.slot_initial(name))
                 if svc.region is not None:
-                    # slots live in the region, behind the variables: m / momentum first, v second
-                    k = 2 if name == "v" else 1
+                    # slots live in the region, behind the variables, in the optimizer's order (Adam: m, then v)
+                    k = svc.slot_plane(name)
                     s[name] = svc.region.local[k * svc.slot_len:k * svc.slot_len + max(svc.n, 1)]
-                    s[name].zero_()
+                    s[name].fill_(first)
                 else:
-                    s[name] = torch.zeros_like(svc.var)
+                    s[name] = torch.full_like(svc.var, first)
             return s[name]
+
+    def slot_plane(self, name: str) -> int:
+        """Which third of a region holds slot ``name`` (0: the variables)."""
+        return 1 + self.opt.slot_order.index(name)
 
     def _join_data_plane(self):
         if dist.is_initialized():
@@ -368,7 +373,7 @@ class ParameterServerService:
             self.grad = torch.zeros_like(self.var)
         self.step_t = torch.zeros(1, dtype=torch.int64, device=self.device)
         o = layout["optimizer"]
-        self.opt = optimizers.Adam(**o["args"]) if o["name"] == "Adam" else optimizers.SGD(**o["args"])
+        self.opt = optimizers.from_description(o)
         self.beta_powers = optimizers.initial_beta_powers(self.opt, self.device)
         self.shard = ParameterServerService._Shard(self)
         self.opt.create_slots(self.shard)
@@ -380,10 +385,14 @@ class ParameterServerService:
         from .doorbell import OwnerPump
         S = self.slot_len
         self.pump = OwnerPump(device=self.device, owner=self.owner_index, workers=self.num_workers, depth=self.depth,
-                              n=self.n, slot_stride=S, var=self.var, m=self.slots.get("m", self.slots.get("momentum")),
-                              v=self.slots.get("v"), inbox=self.region.local[3 * S:], step=self.step_t,
+                              n=self.n, slot_stride=S, var=self.var, m=self._slot_at(0), v=self._slot_at(1),
+                              inbox=self.region.local[3 * S:], step=self.step_t,
                               beta_powers=self.beta_powers, optimizer=self.opt,
                               ctl_address=self.blocks.block_address(self.owner_index), blocks=self.blocks)
+
+    def _slot_at(self, i: int):
+        order = self.opt.slot_order
+        return self.slots.get(order[i]) if i < len(order) else None
 
     def _quiesce(self):
         """Stop applying (what is launched completes): the shard is stable until ``_release``."""
@@ -499,8 +508,8 @@ class ParameterServerService:
                     if src.data_ptr() != self.var.data_ptr():
                         self.var[:self.n].copy_(src)
                 # (a region owner's variables were put into place by the chief before it queued this request)
-                for s in self.slots.values():
-                    s.zero_()
+                for name, s in self.slots.items():
+                    s.fill_(float(self.opt.slot_initial(name)))
                 self.version = 0
                 self.step_t.fill_(int(req.get("global_step", 0)))
                 from .. import optimizers
@@ -589,7 +598,7 @@ class ParameterServerService:
                 self.cp0.barrier("%s/ckpt/%s/in" % (self.ns, token), self.num_owners, timeout_s=600)
             for suffix, slot in kinds:
                 src = self.var if slot is None else self.slots[slot]
-                plane = 0 if slot is None else (2 if slot == "v" else 1)      # which third of a region holds it
+                plane = 0 if slot is None else self.slot_plane(slot)      # which third of a region holds it
                 for p in self.pieces:
                     if p["lo"] != 0:
                         continue                                   # written by the owner of the variable's first element
@@ -634,7 +643,7 @@ class ParameterServerService:
                     self.var[sl].copy_(r.get_tensor(p["name"]).reshape(-1)[p["lo"]:p["lo"] + p["n"]])
                     for slot, suffix in req["slots"].items():
                         key = "%s/%s" % (p["name"], suffix)
-                        if r.has_tensor(key):
+                        if slot in self.opt.slot_order and r.has_tensor(key):
                             self.shard.slot(slot)[sl].copy_(r.get_tensor(key).reshape(-1)[p["lo"]:p["lo"] + p["n"]])
                 gs = None
                 if r.has_tensor("global_step"):
@@ -818,9 +827,7 @@ class AsyncPSStrategy:
         self.ranges = owner_ranges(store, placement, self.num_owners)
         self.flat_len = store.flat_len
         opt = model.optimizer
-        opt_desc = {"name": opt.name, "args": ({"lr": opt.lr, "beta_1": opt.beta1, "beta_2": opt.beta2,
-                                                "epsilon": opt.epsilon} if opt.name == "Adam"
-                                               else {"lr": opt.lr, "momentum": opt.momentum})}
+        opt_desc = opt.describe()
         self.var_table = [(v.name, v.offset, v.numel, list(v.shape)) for v in store.trainable]
         # does any variable straddle two owners?  (then a checkpoint assembles it in its writer's staging area)
         self.gather = any(p["n"] != p["numel"] for j in range(self.num_owners)

@@ -376,16 +376,15 @@ class OwnerPump:
         self._ticket = torch.zeros(1, dtype=torch.int32, device=self.device) if on_gpu else None
         cfg = _PumpConfig()
         cfg.on_gpu, cfg.owner, cfg.workers, cfg.depth = int(on_gpu), int(owner), int(workers), int(depth)
-        is_adam = optimizer.name == "Adam"
-        cfg.optimizer = 0 if is_adam else 1
+        # the rule and its constants: 0 Adam, 1 SGD, 2 RMSProp (b1 = rho, b2 = epsilon inside the root), 3 Adagrad
+        code, lr, b1, b2, eps, momentum = optimizer.pump_parameters()
+        is_adam = code == 0
+        cfg.optimizer = code
         cfg.n, cfg.slot_stride = int(n), int(slot_stride)
         cfg.var, cfg.m, cfg.v, cfg.inbox = nv.ptr(var), nv.ptr(m), nv.ptr(v), nv.ptr(inbox)
         cfg.step, cfg.beta_powers = nv.ptr(step), nv.ptr(beta_powers if is_adam else None)
         cfg.ticket = nv.ptr(self._ticket)
-        if is_adam:
-            cfg.lr, cfg.b1, cfg.b2, cfg.eps, cfg.momentum = optimizer.lr, optimizer.beta1, optimizer.beta2, optimizer.epsilon, 0.0
-        else:
-            cfg.lr, cfg.b1, cfg.b2, cfg.eps, cfg.momentum = optimizer.lr, 0.0, 0.0, 0.0, optimizer.momentum
+        cfg.lr, cfg.b1, cfg.b2, cfg.eps, cfg.momentum = lr, b1, b2, eps, momentum
         cfg.ctl = ctl_address
         if on_gpu and blocks is not None and blocks.replicas is not None:
             # replica mode: acknowledgements stored into every rank's replica by a kernel behind the apply

@@ -126,9 +126,9 @@ class SyncReplicasStrategy:
         from .. import optimizers
         store, opt = model.store, model.optimizer
         self.slot_shards = {}
-        names = ["m", "v"] if isinstance(opt, optimizers.Adam) else (["momentum"] if getattr(opt, "momentum", 0.0) > 0.0 else [])
-        for name in names:
-            self.slot_shards[name] = torch.zeros(max(self.slot_shard_len, 1), dtype=torch.float32, device=store.device)
+        for name in opt.slot_order:
+            self.slot_shards[name] = torch.full((max(self.slot_shard_len, 1),), float(opt.slot_initial(name)),
+                                                dtype=torch.float32, device=store.device)
         if isinstance(opt, optimizers.Adam) and not getattr(store, "_beta_powers_initialised", False):
             store.beta_powers.copy_(optimizers.initial_beta_powers(opt, store.beta_powers.device))
             store._beta_powers_initialised = True
@@ -326,8 +326,8 @@ class SyncReplicasStrategy:
         if prefix[0]:
             self.restore_slot_shards(model, prefix[0])
         else:
-            for t in self.slot_shards.values():
-                t.zero_()
+            for name, t in self.slot_shards.items():
+                t.fill_(float(model.optimizer.slot_initial(name)))
 
     def _bucket_variables(self, model, b: _Bucket):
         return [v for layer in b.layers for v in layer.variables]
@@ -453,6 +453,6 @@ class _ShardView:
         self.global_step = store.global_step
         self.beta_powers = store.beta_powers
 
-    def slot(self, name: str) -> torch.Tensor:
+    def slot(self, name: str, initial: float = 0.0) -> torch.Tensor:
         b = self._b
         return self._slots[name][b.slot_off:b.slot_off + b.shard_end - b.shard_begin]

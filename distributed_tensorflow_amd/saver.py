@@ -251,7 +251,8 @@ class Saver:
     def _shard_of(self, name: str) -> int:
         if name in self.placement:
             return self.placement[name] % self.num_shards
-        base = name.rsplit("/", 1)[0] if name.rsplit("/", 1)[-1] in ("Adam", "Adam_1", "Momentum") else name
+        suffixes = set(getattr(self.optimizer, "slot_checkpoint_names", {}).values()) | {"Adam", "Adam_1", "Momentum"}
+        base = name.rsplit("/", 1)[0] if name.rsplit("/", 1)[-1] in suffixes else name
         return self.placement.get(base, 0) % self.num_shards
 
     def save(self, save_path: str, global_step: Optional[int] = None, write_state: bool = True,

@@ -209,10 +209,10 @@ class VariableStore:
         self.finalized = True
         return self
 
-    def slot(self, slot_name: str) -> torch.Tensor:
-        """Flat optimizer slot buffer (zeros on first use), same layout as ``flat``."""
+    def slot(self, slot_name: str, initial: float = 0.0) -> torch.Tensor:
+        """Flat optimizer slot buffer (filled with ``initial`` on first use), same layout as ``flat``."""
         if slot_name not in self.slots:
-            self.slots[slot_name] = torch.zeros(self.flat_len, dtype=torch.float32, device=self.device)
+            self.slots[slot_name] = torch.full((self.flat_len,), float(initial), dtype=torch.float32, device=self.device)
         return self.slots[slot_name]
 
     def slot_view(self, slot_name: str, var: Variable) -> torch.Tensor:

@@ -193,6 +193,36 @@ def test_sgd(gpu_device):
     torch.testing.assert_close(v2.cpu(), r2, rtol=1e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize("inside", [True, False])
+def test_rmsprop_and_adagrad_kernels(gpu_device, inside):
+    """The accumulator rules on the GPU against the fp32 PyTorch reference of the same op (odd length: scalar tail),
+    with and without the momentum slot, epsilon inside / outside the root, and the fused global_step increment."""
+    n = 10007
+    g0 = torch.Generator().manual_seed(5)
+    var = torch.randn(n, generator=g0)
+    step = torch.zeros(1, dtype=torch.int64, device=gpu_device)
+    for mom_on in (True, False):
+        v, ms, mo = var.to(gpu_device), torch.ones(n, device=gpu_device), (torch.zeros(n, device=gpu_device) if mom_on else None)
+        r, rms, rmo = var.clone(), torch.ones(n), (torch.zeros(n) if mom_on else None)
+        for t in range(4):
+            g = torch.randn(n, generator=g0)
+            F.rmsprop_apply(v, ms, g.to(gpu_device), 0.01, 0.9, mo, 0.7, 1e-7, inside, grad_scale=0.5, advance=step)
+            F.rmsprop_apply(r, rms, g, 0.01, 0.9, rmo, 0.7, 1e-7, inside, grad_scale=0.5)
+        torch.testing.assert_close(v.cpu(), r, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(ms.cpu(), rms, rtol=1e-5, atol=1e-7)
+        if mom_on:
+            torch.testing.assert_close(mo.cpu(), rmo, rtol=1e-5, atol=1e-7)
+    assert step.item() == 8
+    v, acc, r, racc = var.to(gpu_device), torch.full((n,), 0.1, device=gpu_device), var.clone(), torch.full((n,), 0.1)
+    for t in range(4):
+        g = torch.randn(n, generator=g0)
+        F.adagrad_apply(v, acc, g.to(gpu_device), 0.05, 1e-8, inside, advance=step)
+        F.adagrad_apply(r, racc, g, 0.05, 1e-8, inside)
+    torch.testing.assert_close(v.cpu(), r, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(acc.cpu(), racc, rtol=1e-6, atol=1e-7)
+    assert step.item() == 12
+
+
 def test_xor_generator_matches_cpu(gpu_device):
     x, y = F.xor_data(5000, 32, 77, gpu_device)
     xc, yc = F.xor_data(5000, 32, 77, "cpu")
