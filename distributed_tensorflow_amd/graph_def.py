@@ -12,6 +12,20 @@ checkpoint writers encode theirs)::
                  map<string, AttrValue> attr = 5 }
     AttrValue  { DataType type = 6; TensorShapeProto shape = 7 }
     TensorShapeProto { repeated Dim dim = 2 { int64 size = 1 } }
+
+``encode_meta_graph_def`` wraps the same GraphDef into the ``MetaGraphDef`` that TF's saver writes next to every
+checkpoint as ``model.ckpt-<step>.meta``::
+
+    MetaGraphDef { MetaInfoDef meta_info_def = 1 { repeated string tags = 4; string tensorflow_version = 5 }
+                   GraphDef graph_def = 2; SaverDef saver_def = 3; map<string, CollectionDef> collection_def = 4 }
+    SaverDef     { string filename_tensor_name = 1; string save_tensor_name = 2; string restore_op_name = 3;
+                   int32 max_to_keep = 4; bool sharded = 5; float keep_checkpoint_every_n_hours = 6; version = 7 (V2 = 2) }
+    CollectionDef { NodeList node_list = 1 { repeated string value = 1 } | BytesList bytes_list = 2 { repeated bytes value = 1 } }
+    VariableDef  { string variable_name = 1; string initializer_name = 2; string snapshot_name = 3; bool trainable = 7 }
+
+Variable interoperability needs only the ``.index`` / ``.data`` files; the ``.meta`` file completes the set of files a
+TF checkpoint directory holds and lets tools list the graph and its variable collections.  No TensorFlow is available
+to import it with: parity of this file is unpinned, its own decoder (``parse_meta_graph_def``) is what the tests use.
 """
 from __future__ import annotations
 
@@ -75,6 +89,34 @@ def encode_graph_def(nodes: Sequence[Node]) -> bytes:
     """Serialized ``GraphDef``."""
     out = b"".join(_field_bytes(1, encode_node(n)) for n in nodes)
     return out + _field_bytes(4, _field_varint(1, GRAPH_DEF_PRODUCER))
+
+
+def encode_meta_graph_def(nodes: Sequence[Node], variables: Sequence[Tuple[str, bool]], train_ops: Sequence[str] = (),
+                          max_to_keep: int = 5, sharded: bool = True, producer: str = "distributed_tensorflow_amd") -> bytes:
+    """Serialized ``MetaGraphDef``.  ``variables``: ``(name, trainable)`` of every saved variable."""
+    import struct
+    meta_info = _field_bytes(4, b"train") + _field_bytes(5, producer.encode())
+    saver = (_field_bytes(1, b"save/Const:0") + _field_bytes(2, b"save/Identity:0" if sharded else b"save/control_dependency:0")
+             + _field_bytes(3, b"save/restore_all") + _field_varint(4, int(max_to_keep)) + _field_varint(5, 1 if sharded else 0)
+             + _varint((6 << 3) | 5) + struct.pack("<f", 10000.0) + _field_varint(7, 2))
+
+    def variable_def(name: str, trainable: bool) -> bytes:
+        out = _field_bytes(1, (name + ":0").encode()) + _field_bytes(2, (name + "/Assign").encode()) \
+            + _field_bytes(3, (name + "/read:0").encode())
+        return out + (_field_varint(7, 1) if trainable else b"")
+
+    def collection(key: str, value: bytes) -> bytes:
+        return _field_bytes(4, _field_bytes(1, key.encode()) + _field_bytes(2, value))
+
+    def bytes_list(items: Sequence[bytes]) -> bytes:
+        return _field_bytes(2, b"".join(_field_bytes(1, i) for i in items))
+
+    out = _field_bytes(1, meta_info) + _field_bytes(2, encode_graph_def(nodes)) + _field_bytes(3, saver)
+    out += collection("variables", bytes_list([variable_def(n, t) for n, t in variables]))
+    out += collection("trainable_variables", bytes_list([variable_def(n, t) for n, t in variables if t]))
+    if train_ops:
+        out += collection("train_op", _field_bytes(1, b"".join(_field_bytes(1, t.encode()) for t in train_ops)))
+    return out
 
 
 _DT_NAMES = {DT_FLOAT: "DT_FLOAT", DT_INT64: "DT_INT64", DT_BOOL: "DT_BOOL"}
@@ -144,6 +186,52 @@ def parse_graph_def(data: bytes) -> List[Dict]:
                 node["attr"][kv[1].decode()] = kv.get(2, b"")
         nodes.append(node)
     return nodes
+
+
+def parse_meta_graph_def(data: bytes) -> Dict:
+    """Independent decoder of what ``encode_meta_graph_def`` writes: ``{tags, producer, nodes, saver: {...},
+    collections: {key: [variable names] | [node names]}}``."""
+    import struct
+
+    def fields(buf: bytes):
+        pos = 0
+        while pos < len(buf):
+            key, pos = _read_varint(buf, pos)
+            num, wt = key >> 3, key & 7
+            if wt == 0:
+                v, pos = _read_varint(buf, pos)
+            elif wt == 2:
+                ln, pos = _read_varint(buf, pos)
+                v, pos = buf[pos:pos + ln], pos + ln
+            elif wt == 5:
+                v, pos = buf[pos:pos + 4], pos + 4
+            else:
+                raise ValueError("unsupported wire type %d" % wt)
+            yield num, v
+
+    out: Dict = {"tags": [], "producer": "", "nodes": [], "saver": {}, "collections": {}}
+    for num, v in fields(data):
+        if num == 1:
+            for f, fv in fields(v):
+                if f == 4:
+                    out["tags"].append(fv.decode())
+                elif f == 5:
+                    out["producer"] = fv.decode()
+        elif num == 2:
+            out["nodes"] = parse_graph_def(v)
+        elif num == 3:
+            names = {1: "filename_tensor_name", 2: "save_tensor_name", 3: "restore_op_name", 4: "max_to_keep", 5: "sharded",
+                     6: "keep_checkpoint_every_n_hours", 7: "version"}
+            for f, fv in fields(v):
+                out["saver"][names[f]] = fv.decode() if f <= 3 else (struct.unpack("<f", fv)[0] if f == 6 else fv)
+        elif num == 4:
+            kv = dict(fields(v))
+            key, items = kv[1].decode(), []
+            for kind, body in fields(kv[2]):
+                for _, item in fields(body):
+                    items.append(dict(fields(item))[1].decode() if kind == 2 else item.decode())
+            out["collections"][key] = items
+    return out
 
 
 def _read_varint(buf: bytes, pos: int) -> Tuple[int, int]:

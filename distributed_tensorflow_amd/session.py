@@ -248,9 +248,30 @@ class CheckpointSaverHook(SessionRunHook):
             pass
 
     def _save(self, session, step: int):
-        session.save_checkpoint(os.path.join(self.dir, self.basename), step, saver=self.saver)
+        prefix = session.save_checkpoint(os.path.join(self.dir, self.basename), step, saver=self.saver)
         self._last_time, self._last_step = time.time(), step
         self.saved_steps.append(step)
+        if session.is_chief and prefix:
+            self._write_meta(session, prefix)
+
+    def _write_meta(self, session, prefix: str):
+        """``<prefix>.meta``: the MetaGraphDef TF's saver writes with every checkpoint (graph, SaverDef, the variable
+        collections).  Encoded once per session; the saver's clean-up removes it with the checkpoint it belongs to."""
+        try:
+            if getattr(self, "_meta", None) is None:
+                from . import graph_def as gd
+                store = session.engine.store
+                variables = [(v.name, bool(v.trainable)) for v in store.variables.values()] + [("global_step", False)]
+                nodes = gd.nodes_for(session.graph)
+                train_ops = [n.name for n in nodes if n.op == "AssignAdd" and "global_step" in n.inputs]
+                saver = session._saver(self.saver)
+                self._meta = gd.encode_meta_graph_def(nodes, variables, train_ops,
+                                                      max_to_keep=getattr(saver, "max_to_keep", 5) or 0,
+                                                      sharded=getattr(saver, "num_shards", 1) > 1)
+            with open(prefix + ".meta", "wb") as f:
+                f.write(self._meta)
+        except (OSError, AttributeError, KeyError, TypeError):
+            pass        # the file is not needed to restore; a model the GraphDef cannot be derived for goes without
 
     def after_run(self, run_context, run_values):
         s = run_context.session

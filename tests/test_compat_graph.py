@@ -81,6 +81,17 @@ def test_reference_style_training_checkpoint_and_resume(tmp_path):
     assert variables["dense_1/kernel"] == (64, 128) and variables["dense_3/bias"] == (32,)
     assert variables["global_step"] == () and "beta1_power" in variables
     assert "dense_2/kernel/Adam" in variables and "dense_2/kernel/Adam_1" in variables
+    # ... including the MetaGraphDef next to the checkpoint: graph, SaverDef and the variable collections
+    from distributed_tensorflow_amd import graph_def as gd
+    assert "model.ckpt-60.meta" in names
+    meta = gd.parse_meta_graph_def(open(ck + ".meta", "rb").read())
+    assert meta["tags"] == ["train"] and meta["saver"]["version"] == 2 and meta["saver"]["max_to_keep"] == 5
+    assert meta["saver"]["restore_op_name"] == "save/restore_all"
+    assert {n["name"] for n in meta["nodes"]} >= {"dense_1/kernel", "dense_1/MatMul", "global_step"}
+    assert "dense_3/bias:0" in meta["collections"]["trainable_variables"]
+    assert "global_step:0" in meta["collections"]["variables"] \
+        and "global_step:0" not in meta["collections"]["trainable_variables"]
+    assert meta["collections"]["train_op"]
 
     # event files: the explicit writer (epoch-numbered steps) and the chief's hooks (true global steps)
     events = [read_events(p) for p in glob.glob(os.path.join(logdir, "events.out.tfevents.*"))]
