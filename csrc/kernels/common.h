@@ -9,7 +9,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define DTF_API extern "C" __attribute__((visibility("default")))
 
 // Activation codes shared with the Python side (ops/_native.py).
-enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2 };
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2,
+       ACT_TANH = 3 };   // tanh: stand-alone activation / activation-gradient kernels only (the GEMM epilogues fuse relu and sigmoid)
 
 #define DTF_CHECK_LAUNCH()                               \
     do {                                                 \

@@ -11,7 +11,7 @@ inline int ew_grid(long long n4) {
 }
 
 // dZ = dY * act'(Y).  relu: (Y > 0) * scale (scale carries a fused dropout's 1/keep);
-// sigmoid: Y (1 - Y); none: copy * scale.
+// sigmoid: Y (1 - Y); tanh: 1 - Y^2; none: copy * scale.
 __global__ __launch_bounds__(256) void act_grad_kernel(const float* __restrict__ dY, const float* __restrict__ Y,
                                                        float* __restrict__ dZ, long long n, int act, float scale) {
     const long long stride = (long long)gridDim.x * blockDim.x;
@@ -20,6 +20,7 @@ __global__ __launch_bounds__(256) void act_grad_kernel(const float* __restrict__
         float r;
         if (act == ACT_RELU) r = (y > 0.f) ? g * scale : 0.f;
         else if (act == ACT_SIGMOID) r = g * y * (1.0f - y);
+        else if (act == ACT_TANH) r = g * (1.0f - y * y);
         else r = g * scale;
         dZ[i] = r;
     }
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(256) void activation_kernel(const float* __restrict
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const float x = X[i];
-        Y[i] = (act == ACT_RELU) ? fmaxf(x, 0.f) : (act == ACT_SIGMOID ? dtf_sigmoid(x) : x);
+        Y[i] = (act == ACT_RELU) ? fmaxf(x, 0.f) : (act == ACT_SIGMOID ? dtf_sigmoid(x) : (act == ACT_TANH ? tanhf(x) : x));
     }
 }
 }  // namespace

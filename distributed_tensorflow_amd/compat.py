@@ -277,6 +277,7 @@ def argmax(x, axis=None, name=None): return Tensor("argmax", [x], {"axis": axis}
 def reduce_mean(x, axis=None, name=None): return Tensor("reduce_mean", [x], {"axis": axis}, name=name)
 def reduce_sum(x, axis=None, name=None): return Tensor("reduce_sum", [x], {"axis": axis}, name=name)
 def sigmoid(x, name=None): return Tensor("sigmoid", [x], name=name)
+def tanh(x, name=None): return Tensor("tanh", [x], name=name)
 def matmul(a, b, transpose_a=False, transpose_b=False, name=None):
     if transpose_a or transpose_b:
         raise NotImplementedError("tf.matmul: transposed operands are not supported by the graph front end")
@@ -294,7 +295,7 @@ def _nn_dropout(x, keep_prob, noise_shape=None, seed=None, name=None):
 
 def _layers_dense(inputs, units, activation=None, use_bias=True, kernel_initializer=None, name=None, **_):
     """``tf.layers.dense``: the functional spelling of ``keras.layers.Dense(units, activation)(inputs)``."""
-    act = {None: None, _relu: "relu", sigmoid: "sigmoid", _softmax: "softmax"}.get(activation, activation)
+    act = {None: None, _relu: "relu", sigmoid: "sigmoid", tanh: "tanh", _softmax: "softmax"}.get(activation, activation)
     return _Dense(units, activation=act, use_bias=use_bias, name=name)(inputs)
 
 
@@ -333,6 +334,7 @@ def _eval_generic(node, env: Dict[Tensor, torch.Tensor], engine: "GraphEngine", 
     elif op == "mul": out = ins[0] * ins[1]
     elif op == "div": out = ins[0] / ins[1]
     elif op == "sigmoid": out = torch.sigmoid(ins[0])
+    elif op == "tanh": out = torch.tanh(ins[0])
     elif op == "relu": out = torch.relu(ins[0])
     elif op == "softmax": out = torch.softmax(ins[0], dim=-1)
     elif op == "matmul": out = ins[0] @ ins[1]
@@ -489,13 +491,13 @@ class GraphEngine(ModelEngine):
                 self.lowered[node] = (layer, node.inputs[0])
                 node = node.inputs[0]
                 continue
-            if node.op not in ("relu", "sigmoid", "softmax", "add", "bias_add", "matmul"):
+            if node.op not in ("relu", "sigmoid", "tanh", "softmax", "add", "bias_add", "matmul"):
                 raise NotImplementedError(
                     "op %r (node %r) is not supported on the model path: the graph front end lowers chains of Keras "
                     "layers, tf.layers.dense, tf.matmul(x, W) [+ b / tf.nn.bias_add] [tf.nn.relu | tf.sigmoid | "
                     "tf.nn.softmax] and tf.nn.dropout applied to one placeholder" % (node.op, node.name))
             top, act, n = node, None, node
-            if n.op in ("relu", "sigmoid", "softmax"):
+            if n.op in ("relu", "sigmoid", "tanh", "softmax"):
                 act, n = n.op, n.inputs[0]
             bias = None
             if _match(n, "add") or _match(n, "bias_add"):
@@ -803,7 +805,8 @@ def _sparse_softmax_xent(labels=None, logits=None, name=None, **_):
 nn = types.SimpleNamespace(softmax_cross_entropy_with_logits=_softmax_xent,
                            softmax_cross_entropy_with_logits_v2=_softmax_xent,
                            sparse_softmax_cross_entropy_with_logits=_sparse_softmax_xent,
-                           sigmoid=sigmoid, relu=_relu, softmax=_softmax, bias_add=_bias_add, dropout=_nn_dropout)
+                           sigmoid=sigmoid, tanh=tanh, relu=_relu, softmax=_softmax, bias_add=_bias_add,
+                           dropout=_nn_dropout)
 layers = types.SimpleNamespace(dense=_layers_dense)
 
 summary = types.SimpleNamespace(scalar=_summary.scalar, merge_all=_summary.merge_all, merge=_summary.merge,

@@ -107,7 +107,7 @@ class Dense(Layer):
         else:
             self.softmax = False
         if activation not in ACT_CODES:
-            raise ValueError("unsupported activation %r (have: relu, sigmoid, softmax, linear)" % (activation,))
+            raise ValueError("unsupported activation %r (have: relu, sigmoid, tanh, softmax, linear)" % (activation,))
         self.activation = activation
         self.act = ACT_CODES[activation]
         self.use_bias = use_bias
@@ -246,8 +246,8 @@ class Activation(Layer):
 
     def __init__(self, activation, name=None):
         super().__init__(name=name)
-        if activation not in ("relu", "sigmoid"):
-            raise ValueError("Activation layer supports relu / sigmoid")
+        if activation not in ("relu", "sigmoid", "tanh"):
+            raise ValueError("Activation layer supports relu / sigmoid / tanh")
         self.activation = activation
         self.act = ACT_CODES[activation]
         self._buf = _Buffers()
@@ -314,7 +314,7 @@ class Conv2D(Layer):
         if self.padding not in ("valid", "same"):
             raise ValueError("padding must be 'valid' or 'same'")
         if activation not in ACT_CODES:
-            raise ValueError("unsupported activation %r (have: relu, sigmoid, linear)" % (activation,))
+            raise ValueError("unsupported activation %r (have: relu, sigmoid, tanh, linear)" % (activation,))
         self.activation = activation
         self.act = ACT_CODES[activation]
         self.use_bias = use_bias

@@ -88,7 +88,7 @@ class GraphModel(Sequential):
             elif n.op in ("add", "sub", "mul", "div", "bias_add"):
                 shapes[id(n)] = ins[0] if ins[0] is not None and (not _is_node(n.inputs[0]) or n.inputs[0].op != "Variable") \
                     else (ins[1] if len(ins) > 1 else None)
-            elif n.op in ("relu", "sigmoid", "softmax", "nn_dropout", "round", "square", "cast"):
+            elif n.op in ("relu", "sigmoid", "tanh", "softmax", "nn_dropout", "round", "square", "cast"):
                 shapes[id(n)] = ins[0]
             else:
                 shapes[id(n)] = None
@@ -152,7 +152,7 @@ class GraphModel(Sequential):
         if isinstance(layer, L.Conv2D):
             b = self._leaf(layer.bias) if layer.bias is not None else None
             return A.conv2d(x, self._leaf(layer.kernel), b, layer.strides, layer.padding,
-                            {0: None, 1: "relu", 2: "sigmoid"}[layer.act])
+                            {0: None, 1: "relu", 2: "sigmoid", 3: "tanh"}[layer.act])
         if isinstance(layer, L.MaxPooling2D):
             return A.max_pool2d(x, layer.pool_size, layer.strides, layer.padding)
         raise NotImplementedError("layer %s is not supported in a graph model" % type(layer).__name__)
@@ -202,6 +202,8 @@ class GraphModel(Sequential):
                 out = A.activation(ins[0], "relu")
             elif op == "sigmoid":
                 out = A.activation(ins[0], "sigmoid")
+            elif op == "tanh":
+                out = A.activation(ins[0], "tanh")
             elif op == "softmax":
                 out = torch.softmax(ins[0], dim=-1)
             elif op == "nn_dropout":

@@ -15,8 +15,9 @@ import torch
 
 LIB_DIR = Path(__file__).resolve().parent.parent / "_lib"
 
-ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
-ACT_CODES = {None: ACT_NONE, "linear": ACT_NONE, "none": ACT_NONE, "relu": ACT_RELU, "sigmoid": ACT_SIGMOID}
+ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
+ACT_CODES = {None: ACT_NONE, "linear": ACT_NONE, "none": ACT_NONE, "relu": ACT_RELU, "sigmoid": ACT_SIGMOID,
+             "tanh": ACT_TANH}
 
 _kernels = None
 _runtime = None

@@ -19,7 +19,7 @@ from typing import Optional
 import torch
 
 from . import functional as F
-from ._native import ACT_CODES, ACT_NONE, ACT_RELU, ACT_SIGMOID
+from ._native import ACT_CODES, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH
 
 
 def _c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
@@ -38,8 +38,8 @@ class _DenseFn(torch.autograd.Function):
         x, w, b = _c(x), _c(w), _c(b)
         lead = x.shape[:-1]
         x2 = x.reshape(-1, x.shape[-1])
-        if act == ACT_SIGMOID and keep < 1.0:
-            raise ValueError("dropout fused behind a sigmoid is not supported: apply `dropout` as a separate op")
+        if act in (ACT_SIGMOID, ACT_TANH) and keep < 1.0:
+            raise ValueError("dropout fused behind a sigmoid / tanh is not supported: apply `dropout` as a separate op")
         y = F.dense_forward(x2, w, b, act=act, keep=keep, seed=seed, step=step)
         ctx.save_for_backward(x2, w, y)
         ctx.cfg = (act, keep, seed, step, b is not None, lead)
@@ -53,7 +53,7 @@ class _DenseFn(torch.autograd.Function):
         if act == ACT_NONE:
             dz = F.dropout(dy2, keep, seed, step) if keep < 1.0 else dy2     # the same mask as in the forward pass
         else:
-            # relu (+dropout): (y > 0) / keep - a dropped element is zero in y; sigmoid: y (1 - y)
+            # relu (+dropout): (y > 0) / keep - a dropped element is zero in y; sigmoid: y (1 - y); tanh: 1 - y^2
             dz = F.act_grad(dy2, y, act, scale=1.0 / keep)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:

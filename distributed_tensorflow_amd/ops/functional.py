@@ -16,7 +16,7 @@ from __future__ import annotations
 import torch
 
 from . import _native as nv
-from ._native import ACT_CODES, ACT_NONE, ACT_RELU, ACT_SIGMOID  # noqa: F401
+from ._native import ACT_CODES, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH  # noqa: F401
 
 _M32 = 0xFFFFFFFF
 
@@ -70,6 +70,8 @@ def _apply_act(z: torch.Tensor, act: int) -> torch.Tensor:
         return torch.relu(z)
     if act == ACT_SIGMOID:
         return torch.sigmoid(z)
+    if act == ACT_TANH:
+        return torch.tanh(z)
     return z
 
 
@@ -118,6 +120,12 @@ def dense_forward(x, w, b=None, act=ACT_NONE, keep=1.0, seed=0, step=None, out=N
         nv.require_f32_contig(x, w, b, out)
         if step is not None:
             assert step.dtype == torch.int64 and step.is_cuda
+        if act == ACT_TANH:
+            # the GEMM epilogues fuse relu and sigmoid; tanh is one more pass over the output, in place
+            if keep < 1.0:
+                raise ValueError("dropout is fused into relu layers only")
+            dense_forward(x, w, b, ACT_NONE, 1.0, seed, step, out, workspace, bf16)
+            return activation_forward(out, ACT_TANH, out=out)
         if bf16:
             rc = nv.kernels().dtf_dense_fwd_bf16(nv.ptr(x), nv.ptr(w), nv.ptr(b), nv.ptr(out), M, N, K, int(act),
                                                  float(keep), int(seed) & _M32, nv.ptr(step), nv.stream_ptr())
@@ -216,6 +224,8 @@ def act_grad(dy, y, act, scale=1.0, out=None):
         r = torch.where(y > 0, dy * scale, torch.zeros_like(dy))
     elif act == ACT_SIGMOID:
         r = dy * y * (1.0 - y)
+    elif act == ACT_TANH:
+        r = dy * (1.0 - y * y)
     else:
         r = dy * scale
     out.copy_(r)
@@ -1007,6 +1017,11 @@ def conv_gemm_forward(xpad, rowtab, shift, w2d, bias, act, out, masktab=None, po
     M = rowtab.numel()
     C = xpad.shape[-1]
     nv.require_f32_contig(xpad, w2d, bias, out)
+    if act == ACT_TANH:
+        if pool_arg is not None:
+            raise ValueError("the pooling epilogue fuses relu / linear convolutions only")
+        conv_gemm_forward(xpad, rowtab, shift, w2d, bias, ACT_NONE, out, masktab)
+        return activation_forward(out, ACT_TANH, out=out)
     rc = nv.kernels().dtf_conv_gemm_fwd(nv.ptr(xpad), xpad.numel(), nv.ptr(rowtab), nv.ptr(shift), C, nv.ptr(w2d), nv.ptr(bias),
                                         nv.ptr(out), M, N, K, int(act), nv.ptr(masktab), nv.ptr(pool_arg),
                                         nv.stream_ptr())
