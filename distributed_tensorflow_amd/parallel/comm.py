@@ -138,6 +138,16 @@ class Communicator:
             return None
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
 
+    def all_reduce_max(self, t: torch.Tensor):
+        if self.world_size == 1:
+            return None
+        if self._staged(t):
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.MAX, group=self.group)
+            t.copy_(h)
+            return None
+        return dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+
     def broadcast(self, t: torch.Tensor, src: int = 0, async_op: bool = False):
         if self.world_size == 1:
             return None

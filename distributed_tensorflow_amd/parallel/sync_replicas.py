@@ -429,13 +429,26 @@ class SyncReplicasStrategy:
         complete on every replica; sharded slots are written by ``save_sharded``."""
         self.check_exchange()                             # never checkpoint past a failed gradient exchange
 
-    def agree(self, flag: bool) -> bool:
-        """The chief's boolean decision, on every replica (one tiny broadcast)."""
+    def agree(self, flag: bool, step: Optional[int] = None) -> bool:
+        """The chief's boolean decision, on every replica (one tiny all-reduce).
+
+        With ``step`` (the caller's ``global_step``) the same exchange checks that the replicas are in step.
+        ``tf.train.SyncReplicasOptimizer`` drops a gradient whose ``local_step`` is behind ``global_step``; here a
+        gradient can only be stale if a replica's counter has left the group's (replicas apply one aggregated update
+        per collective, in lock step), and that replica's variables are then suspect too - so every replica raises
+        ``ClusterLostError`` and the launcher restarts the gang from the last checkpoint, which drops the stale work."""
         if self.world_size == 1:
             return bool(flag)
-        t = torch.tensor([1 if flag else 0], dtype=torch.int64, device=getattr(self, "_device", "cpu"))
-        self.comm.broadcast(t, 0)
-        return bool(t.item())
+        s = int(step) if step is not None else 0
+        t = torch.tensor([1 if (flag and self.rank == 0) else 0, s, -s], dtype=torch.int64,
+                         device=getattr(self, "_device", "cpu"))
+        self.comm.all_reduce_max(t)
+        decision, hi, lo = (int(v) for v in t.tolist())
+        if step is not None and hi != -lo:
+            from ..failure import ClusterLostError
+            raise ClusterLostError("synchronous replicas are out of step: global_step ranges from %d to %d (this replica, "
+                                   "rank %d: %d)" % (-lo, hi, self.rank, s))
+        return bool(decision)
 
     collective_checkpoint = True
 

@@ -288,7 +288,7 @@ class CheckpointSaverHook(SessionRunHook):
             # clock, consulted every `poll_steps` steps so that the broadcast stays off the per-step path
             if step % self.poll_steps != 0:
                 return
-            due = agree(due)
+            due = agree(due, step)
         if due and step != self._last_step:
             self._save(s, step)
 

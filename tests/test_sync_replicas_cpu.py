@@ -151,3 +151,51 @@ def test_sharded_slots_resume_bit_exact(tmp_path):
         assert all((res[0][1] == r[1]).all() for r in res[1:])
     assert (finals[0][1] == finals[1][1]).all()          # variables
     assert (finals[0][2] == finals[1][2]).all() and float(abs(finals[0][2]).sum()) > 0       # Adam's v
+
+
+def _out_of_step_worker(rank, world, port, out_q):
+    sys.path.insert(0, ROOT)
+    torch.set_num_threads(1)
+    from distributed_tensorflow_amd.data import mnist_like
+    from distributed_tensorflow_amd.failure import ClusterLostError
+    from distributed_tensorflow_amd.layers import Dense
+    from distributed_tensorflow_amd.models import Sequential
+    from distributed_tensorflow_amd.parallel import Communicator, SyncReplicasStrategy, init_process_group
+    init_process_group("gloo", rank=rank, world_size=world, master_addr="127.0.0.1", master_port=port)
+    m = Sequential([Dense(16, input_dim=784, activation="relu"), Dense(10, activation="softmax")])
+    strat = SyncReplicasStrategy(Communicator())
+    m.compile(loss="sparse_categorical_crossentropy", optimizer="adam", strategy=strat, device="cpu", seed=1)
+    x, y = mnist_like(32, seed=rank)
+    seen = []
+    for i in range(4):
+        m.train_step(x, y)
+        if i == 2 and rank == 1:
+            m.store.global_step += 1          # this replica's counter leaves the group's (a stale or repeated update)
+        try:
+            seen.append(strat.agree(i == 1, int(m.store.global_step.item())))
+        except ClusterLostError as e:
+            seen.append(str(e))
+            break
+    out_q.put((rank, seen))
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+def test_replicas_out_of_step_are_detected():
+    """One aggregated update per collective keeps every replica's ``global_step`` equal; the periodic agreement
+    exchange (the chief's checkpoint decision) doubles as the check, and a replica whose counter has left the group
+    makes EVERY replica raise - the lock-step counterpart of SyncReplicasOptimizer dropping stale gradients."""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_out_of_step_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        assert res[rank][:2] == [False, True]                  # in step: the chief's decision reaches everybody
+        assert "out of step" in res[rank][2] and "from 3 to 4" in res[rank][2]
