@@ -575,8 +575,11 @@ class Sequential:
     def fit(self, x, y, epochs: int = 1, batch_size: int = 32, validation_data=None, callbacks=None,
             shuffle: bool = True, verbose: int = 1, steps_per_graph: int = 0, initial_epoch: int = 0,
             fused: Optional[bool] = None, stream_from_host: bool = False, shuffle_seed: int = 0,
-            async_workers: Optional[int] = None):
+            async_workers: Optional[int] = None, validation_split: float = 0.0):
         """Keras ``fit``.  Data is moved to the device once; each epoch reshuffles on the device.
+
+        ``validation_split`` (ignored when ``validation_data`` is given): that fraction of the examples, taken from
+        the END of ``x`` / ``y`` before any shuffling, is held out and evaluated after every epoch (Keras' rule).
 
         ``stream_from_host=True`` keeps ``x`` / ``y`` in host memory instead (data sets larger than HBM): C++ worker
         threads gather each epoch's shuffled batches into pinned buffers and a copy stream moves them to the device
@@ -592,6 +595,14 @@ class Sequential:
         if async_workers is not None:
             self.async_workers = max(1, int(async_workers))
         self._check_compiled()
+        if validation_data is None and validation_split:
+            if not 0.0 < validation_split < 1.0:
+                raise ValueError("validation_split must be in (0, 1)")
+            cut = int(len(x) * (1.0 - validation_split))
+            if cut <= 0 or cut >= len(x):
+                raise ValueError("validation_split=%r leaves no training or no validation examples" % validation_split)
+            validation_data = (x[cut:], y[cut:])
+            x, y = x[:cut], y[:cut]
         if stream_from_host:
             return self._fit_streamed(x, y, epochs, batch_size, validation_data, callbacks, shuffle, verbose,
                                       initial_epoch, shuffle_seed)

@@ -124,3 +124,29 @@ def test_model_save_and_load_model_rebuild_architecture_and_state(tmp_path):
     assert twin.get_config()["layers"] == cnn.get_config()["layers"]
     twin.build(device="cpu")
     assert twin.store.num_params == 5 * 5 * 32 + 32 + 5 * 5 * 32 * 64 + 64 + 3136 * 512 + 512 + 5120 + 10
+
+
+def test_fit_validation_split_holds_out_the_tail():
+    import torch
+    from distributed_tensorflow_amd.data import get_data
+    from distributed_tensorflow_amd.models import xor_mlp
+    x, y, _, _ = get_data(1000, val_set_size=0, seed=2)
+    seen = {}
+
+    from distributed_tensorflow_amd.callbacks import Callback
+
+    class Spy(Callback):
+        def on_train_begin(self, logs=None):
+            seen["samples"] = self.params["samples"]
+
+    m = xor_mlp(dropout=0.0)
+    m.compile(loss="mean_squared_error", optimizer="adam", metrics=["binary_rounded_accuracy"], device="cpu", seed=1)
+    h = m.fit(x, y, epochs=2, batch_size=50, validation_split=0.2, verbose=0, shuffle=False, callbacks=[Spy()])
+    assert seen["samples"] == 800 and m.global_step == 2 * 16
+    assert "val_loss" in h.history and len(h.history["val_loss"]) == 2
+    # the held-out part is the LAST fifth of the data
+    want = m.evaluate(x[800:], y[800:], batch_size=200)[0]
+    assert abs(h.history["val_loss"][-1] - want) < 1e-6
+    import pytest
+    with pytest.raises(ValueError):
+        m.fit(x, y, epochs=1, batch_size=50, validation_split=1.5, verbose=0)
