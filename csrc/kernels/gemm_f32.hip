@@ -80,6 +80,8 @@ struct GemmArgs {
     int single_lds;           // one LDS stage instead of two (tuning aid DTF_GEMM_SINGLE): half the LDS per block, so twice
                               // the resident blocks, for a second barrier per k tile
     int dbg;                  // DTF_GEMM_DBG bit 8: every block stamps its main-loop time over its first outputs; 0 in production
+    int xcd_remap;            // walk the grid so that the blocks one XCD receives (every eighth in dispatch order) are
+                              // NEIGHBOURS in the grid: they share operand panels, and an XCD has its own L2
     // implicit-GEMM convolution (GATHER kernels): operand A is the patch matrix of a zero-padded NHWC image that is
     // never materialised.  Patch row m starts at element g_rowtab[m] of the image; window position w = k / g_C
     // adds g_shift[w]; the channel k % g_C is contiguous.
@@ -482,8 +484,8 @@ struct PickLoader<true, ROWS, KC> { using type = GatherLoader<ROWS, KC>; };
 // operand type): col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
 template <int TM, int TN, int BM, int BN, int EPI>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int li,
-                                              int h) {
-    float* C = p.C + (long long)blockIdx.z * p.c_split_stride;
+                                              int h, int bz) {
+    float* C = p.C + (long long)bz * p.c_split_stride;
     if (EPI == EPI_FWD && p.pool_arg) {
         // 2x2 max pooling in registers: in the C/D layout of the 32x32 MFMA the four registers 4q..4q+3 of a lane are
         // four CONSECUTIVE rows, and the row order of the patch table makes those the four pixels of one pooling
@@ -547,7 +549,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
                 for (int r = 0; r < 16; ++r) {
                     const int dr = (r & 3) + 8 * (r >> 2);
                     if (CHECK && EPI == EPI_DW && p.colsum_mfma && row0 + dr == p.M && p.colsum) {
-                        p.colsum[(long long)blockIdx.z * p.colsum_split_stride + col] = acc[i][j][r];    // ones row . B
+                        p.colsum[(long long)bz * p.colsum_split_stride + col] = acc[i][j][r];    // ones row . B
                         continue;
                     }
                     if (CHECK && row0 + dr >= p.M) continue;
@@ -617,9 +619,25 @@ void gemm_f32_kernel(const GemmArgs p) {
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 31, h = lane >> 5;
 
-    const int m0 = blockIdx.y * BM;
-    const int n0 = blockIdx.x * BN;
-    const int kbeg = blockIdx.z * p.k_chunk;
+    // Which tile / K split this block computes.  Workgroups are dealt to the 8 XCDs round-robin in dispatch order
+    // (x fastest, then y, then z), and every XCD has its own L2: with the plain mapping the blocks that share an
+    // operand panel - the row tiles of one K split of a wgrad all read the same slab of dZ - sit on eight different
+    // L2s and each fetches the panel for itself.  Remapped, the blocks with equal (dispatch index mod 8) take a
+    // contiguous run of the grid (bijective also when the block count is no multiple of 8).
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (p.xcd_remap) {
+        const int gx = gridDim.x, gy = gridDim.y;
+        const int nwg = gx * gy * (int)gridDim.z;
+        const int lin = bx + gx * (by + gy * bz);
+        const int q = nwg >> 3, r = nwg & 7, xcd = lin & 7;
+        const int to = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
+        bx = to % gx;
+        by = (to / gx) % gy;
+        bz = to / (gx * gy);
+    }
+    const int m0 = by * BM;
+    const int n0 = bx * BN;
+    const int kbeg = bz * p.k_chunk;
     const int kend = min(p.K, kbeg + p.k_chunk);
 
     f32x16 acc[TM][TN];
@@ -633,7 +651,7 @@ void gemm_f32_kernel(const GemmArgs p) {
     // does this wave own any output inside C?  (TM x TN sub-tiles starting at its first row / column)
     const bool wave_live = (m0 + wm * TM * 32 < p.M) && (n0 + wn * TN * 32 < p.N);
     float csum = 0.f;  // wgrad: partial bias gradient of column n0 + tid
-    const bool do_colsum = (EPI == EPI_DW) && (p.colsum != nullptr) && (blockIdx.y == 0) && !p.colsum_mfma;
+    const bool do_colsum = (EPI == EPI_DW) && (p.colsum != nullptr) && (by == 0) && !p.colsum_mfma;
 
     LoadA la;
     LoadB lb;
@@ -751,9 +769,9 @@ void gemm_f32_kernel(const GemmArgs p) {
 
     unsigned long long dbg_t1 = 0;
     if (p.dbg & 8) dbg_t1 = __builtin_amdgcn_s_memtime();
-    gemm_epilogue<TM, TN, BM, BN, EPI>(p, acc, m0, n0, wm, wn, li, h);
+    gemm_epilogue<TM, TN, BM, BN, EPI>(p, acc, m0, n0, wm, wn, li, h, bz);
     if ((p.dbg & 8) && tid == 0) {   // timing-only diagnostic: loop cycles and 100 MHz ticks into the tile's first row
-        float* C = p.C + (long long)blockIdx.z * p.c_split_stride;
+        float* C = p.C + (long long)bz * p.c_split_stride;
         C[(long long)m0 * p.ldc + n0] = (float)(__builtin_amdgcn_s_memtime() - dbg_t0);
         C[(long long)m0 * p.ldc + n0 + 1] = (float)(__builtin_amdgcn_s_memrealtime() - dbg_r0);
         C[(long long)m0 * p.ldc + n0 + 2] = (float)(dbg_t1 - dbg_t0);
@@ -765,7 +783,7 @@ void gemm_f32_kernel(const GemmArgs p) {
     }
     if (EPI == EPI_DW) {
         if (do_colsum && tid < BN && (n0 + tid) < p.N)
-            p.colsum[(long long)blockIdx.z * p.colsum_split_stride + n0 + tid] = csum;
+            p.colsum[(long long)bz * p.colsum_split_stride + n0 + tid] = csum;
     }
 }
 
@@ -843,7 +861,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs p) {
         __syncthreads();
         stage ^= 1;
     }
-    gemm_epilogue<TM, TN, BM, BN, EPI>(p, acc, m0, n0, wm, wn, li, h);
+    gemm_epilogue<TM, TN, BM, BN, EPI>(p, acc, m0, n0, wm, wn, li, h, blockIdx.z);
 }
 
 template <bool A_KC, bool B_KC, int EPI>
@@ -958,7 +976,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const GemmArgs p) {
             }
         }
     }
-    gemm_epilogue<TM, TN, BM, BN, EPI>(p, acc, m0, n0, wm, wn, li, h);
+    gemm_epilogue<TM, TN, BM, BN, EPI>(p, acc, m0, n0, wm, wn, li, h, blockIdx.z);
     if ((p.dbg & 8) && tid == 0) {   // timing-only diagnostic: block cycles and 100 MHz ticks over the tile's first outputs
         float* C = p.C + (long long)blockIdx.z * p.c_split_stride;
         C[(long long)m0 * p.ldc + n0] = (float)(__builtin_amdgcn_s_memtime() - dbg_t0);
@@ -1052,6 +1070,11 @@ int launch_cfg(const GemmArgs& a, int splits, hipStream_t s) {
     GemmArgs args = a;
     args.dbg = env_dbg();
     args.single_lds = single;
+    // DTF_GEMM_XCD (tuning aid) is a mask of the kernels that walk their grid XCD by XCD: 1 dense wgrad, 2 the
+    // convolution gathers, 4 dense forward / dgrad
+    static const int xcd_mask = getenv("DTF_GEMM_XCD") ? atoi(getenv("DTF_GEMM_XCD")) : 0;
+    const int xcd_bit = GATHER ? 2 : (EPI == EPI_DW ? 1 : 4);
+    args.xcd_remap = (xcd_mask & xcd_bit) && (long long)grid.x * grid.y * grid.z >= 16 ? 1 : 0;
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, args);
     DTF_CHECK_LAUNCH();
     return 0;
