@@ -862,6 +862,10 @@ class _MaxPooling2D(_SymbolicLayerMixin, _layers.MaxPooling2D):
     pass
 
 
+class _BatchNormalization(_SymbolicLayerMixin, _layers.BatchNormalization):
+    pass
+
+
 class _KerasBackend:
     _session = None
 
@@ -895,7 +899,7 @@ def _keras_bce(y_true, y_pred):
 
 keras = types.SimpleNamespace(
     layers=types.SimpleNamespace(Dense=_Dense, Dropout=_Dropout, Activation=_Activation, Flatten=_Flatten,
-                                 Conv2D=_Conv2D, MaxPooling2D=_MaxPooling2D),
+                                 Conv2D=_Conv2D, MaxPooling2D=_MaxPooling2D, BatchNormalization=_BatchNormalization),
     models=types.SimpleNamespace(Sequential=_Sequential),
     backend=_KerasBackend,
     losses=types.SimpleNamespace(mean_squared_error=_keras_mse, binary_crossentropy=_keras_bce),

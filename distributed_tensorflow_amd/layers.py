@@ -265,6 +265,99 @@ class Activation(Layer):
         return F.act_grad(dy, self._y, self.act, 1.0, out=self._buf.get("dx", dy.shape, dy.device))
 
 
+class BatchNormalization(Layer):
+    """Keras ``BatchNormalization(axis=-1, momentum=0.99, epsilon=1e-3, center=True, scale=True)``: every channel of
+    the last axis is normalised with the statistics of the batch while training (learning phase 1) and with the moving
+    averages otherwise.  Variables as Keras names them: ``gamma`` / ``beta`` (trained), ``moving_mean`` /
+    ``moving_variance`` (not trained; they start at 0 / 1 and follow the batch statistics with ``momentum``).  Works
+    on dense activations ``[B, C]`` and feature maps ``[B, H, W, C]`` alike (rows = everything but the last axis).
+    Under the cluster strategies the moving averages are each replica's own, like the batch statistics."""
+
+    prefix = "batch_normalization"
+
+    def __init__(self, axis: int = -1, momentum: float = 0.99, epsilon: float = 1e-3, center: bool = True,
+                 scale: bool = True, name=None, input_shape=None):
+        super().__init__(name=name, input_shape=input_shape)
+        if axis not in (-1, 3, 1):
+            raise ValueError("BatchNormalization normalises the last axis (axis=-1)")
+        self.axis = axis
+        self.momentum, self.epsilon = float(momentum), float(epsilon)
+        self.center, self.scale = bool(center), bool(scale)
+        self.gamma = self.beta = self.moving_mean = self.moving_variance = None
+        self._buf = _Buffers()
+        self._x = None
+        self._trained = False
+
+    def get_config(self):
+        return {"class": "BatchNormalization", "name": self.name, "axis": -1, "momentum": self.momentum,
+                "epsilon": self.epsilon, "center": self.center, "scale": self.scale}
+
+    def build(self, input_shape, store):
+        out = super().build(input_shape, store)
+        if self.axis != -1 and self.axis != len(input_shape):
+            raise ValueError("BatchNormalization normalises the last axis; got axis=%d for per-example shape %s"
+                             % (self.axis, tuple(input_shape)))
+        c = int(input_shape[-1])
+        if self.scale:
+            self.gamma = store.create(self.name + "/gamma", (c,), "ones")
+        if self.center:
+            self.beta = store.create(self.name + "/beta", (c,), "zeros")
+        self.moving_mean = store.create(self.name + "/moving_mean", (c,), "zeros", trainable=False)
+        self.moving_variance = store.create(self.name + "/moving_variance", (c,), "ones", trainable=False)
+        return out
+
+    @property
+    def variables(self):
+        return [v for v in (self.gamma, self.beta) if v is not None]
+
+    @property
+    def non_trainable_variables(self):
+        return [self.moving_mean, self.moving_variance]
+
+    def _workspace(self, R, C, device):
+        if device.type != "cuda":
+            return None
+        return self._buf.get("ws", (F.batchnorm_workspace_floats(R, C),), device)
+
+    def forward(self, x, training):
+        C = x.shape[-1]
+        x2 = x.reshape(-1, C)
+        R = x2.shape[0]
+        y = self._buf.get("y", x2.shape, x.device)
+        mean = self._buf.get("mean", (C,), x.device)
+        inv = self._buf.get("inv_std", (C,), x.device)
+        F.batchnorm_forward(x2, self.gamma.tensor if self.gamma is not None else None,
+                            self.beta.tensor if self.beta is not None else None, self.moving_mean.tensor,
+                            self.moving_variance.tensor, self.momentum, self.epsilon, training, y, mean, inv,
+                            self._workspace(R, C, x.device))
+        self._x, self._trained = x2, bool(training)
+        return y.view(x.shape)
+
+    def backward(self, dy):
+        x2 = self._x
+        R, C = x2.shape
+        dy2 = dy.reshape(R, C)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        gamma = self.gamma.tensor if self.gamma is not None else None
+        if not self._trained:
+            # learning phase 0 with a training op: the layer is the affine map of the moving statistics
+            inv = 1.0 / torch.sqrt(self.moving_variance.tensor + self.epsilon)
+            xhat = (x2 - self.moving_mean.tensor) * inv
+            if self.gamma is not None:
+                self.gamma.grad.copy_((dy2 * xhat).sum(dim=0))
+            if self.beta is not None:
+                self.beta.grad.copy_(dy2.sum(dim=0))
+            if not self.need_input_grad:
+                return None
+            return (dy2 * (inv if gamma is None else gamma * inv)).view(dy.shape)
+        dx = self._buf.get("dx", x2.shape, x2.device) if self.need_input_grad else None
+        F.batchnorm_backward(x2, dy2, gamma, self._buf.get("mean", (C,), x2.device), self._buf.get("inv_std", (C,), x2.device),
+                             self.gamma.grad if self.gamma is not None else None,
+                             self.beta.grad if self.beta is not None else None, dx, self._workspace(R, C, x2.device))
+        return dx.view(dy.shape) if dx is not None else None
+
+
 class Flatten(Layer):
     prefix = "flatten"
 
@@ -652,7 +745,7 @@ class MaxPooling2D(Layer):
 
 def layer_from_config(cfg: dict) -> Layer:
     """Rebuild a layer from its ``get_config()`` dictionary (``class`` names the layer type)."""
-    classes = {c.__name__: c for c in (Dense, Dropout, Activation, Flatten, Conv2D, MaxPooling2D)}
+    classes = {c.__name__: c for c in (Dense, Dropout, Activation, Flatten, Conv2D, MaxPooling2D, BatchNormalization)}
     kw = {k: v for k, v in cfg.items() if k != "class"}
     try:
         cls = classes[cfg["class"]]

@@ -80,6 +80,8 @@ def kernels():
         "dtf_scale": [c_p, c_ll, c_f, c_p],
         "dtf_init_uniform": [c_p, c_ll, c_u32, c_f, c_f, c_p],
         "dtf_activation": [c_p, c_p, c_ll, c_i, c_p],
+        "dtf_batchnorm_fwd": [c_p, c_p, c_ll, c_i, c_p, c_p, c_p, c_p, c_f, c_f, c_i, c_p, c_p, c_p, c_p],
+        "dtf_batchnorm_bwd": [c_p, c_p, c_p, c_ll, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
         "dtf_softmax_rows": [c_p, c_p, c_i, c_i, c_p],
         "dtf_im2col": [c_p, c_p] + [c_i] * 12 + [c_p],
         "dtf_col2im": [c_p, c_p, c_p] + [c_i] * 12 + [c_p],
@@ -111,6 +113,9 @@ def kernels():
             fn = getattr(lib, name)
             fn.argtypes = argtypes
             fn.restype = c_i
+    if hasattr(lib, "dtf_batchnorm_workspace_floats"):
+        lib.dtf_batchnorm_workspace_floats.argtypes = [c_ll, c_i]
+        lib.dtf_batchnorm_workspace_floats.restype = c_ll
     _kernels = lib
     return lib
 

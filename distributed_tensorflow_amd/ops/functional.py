@@ -264,6 +264,70 @@ def activation_forward(x, act, out=None):
     return out
 
 
+def batchnorm_workspace_floats(R: int, C: int) -> int:
+    """Scratch floats ``batchnorm_forward`` / ``batchnorm_backward`` need on the GPU for ``[R, C]`` activations."""
+    return int(nv.kernels().dtf_batchnorm_workspace_floats(int(R), int(C)))
+
+
+def batchnorm_forward(x, gamma, beta, moving_mean, moving_var, momentum, eps, training, out, save_mean, save_inv_std,
+                      workspace=None):
+    """Batch normalisation over the last axis of ``x`` [R, C] (Keras ``BatchNormalization(axis=-1)``).
+
+    ``training``: normalise with the batch's mean and (biased) variance, keep them in ``save_mean`` / ``save_inv_std``
+    for the backward pass and move ``moving_mean`` / ``moving_var`` towards them (``m <- momentum m + (1 - momentum)
+    batch``); else normalise with the moving statistics.  ``gamma`` / ``beta`` may be None."""
+    R, C = x.shape
+    if x.is_cuda:
+        nv.require_f32_contig(x, gamma, beta, moving_mean, moving_var, out, save_mean, save_inv_std, workspace)
+        assert workspace is not None and workspace.numel() >= batchnorm_workspace_floats(R, C)
+        rc = nv.kernels().dtf_batchnorm_fwd(nv.ptr(x), nv.ptr(out), R, C, nv.ptr(gamma), nv.ptr(beta), nv.ptr(moving_mean),
+                                            nv.ptr(moving_var), float(momentum), float(eps), int(bool(training)),
+                                            nv.ptr(save_mean), nv.ptr(save_inv_std), nv.ptr(workspace), nv.stream_ptr())
+        nv.check(rc, "dtf_batchnorm_fwd")
+        return out
+    if training:
+        mean = x.mean(dim=0)
+        var = x.var(dim=0, unbiased=False)
+        save_mean.copy_(mean)
+        save_inv_std.copy_(1.0 / torch.sqrt(var + eps))
+        moving_mean.mul_(momentum).add_(mean, alpha=1.0 - momentum)
+        moving_var.mul_(momentum).add_(var, alpha=1.0 - momentum)
+        inv = save_inv_std
+    else:
+        mean, inv = moving_mean, 1.0 / torch.sqrt(moving_var + eps)
+    y = (x - mean) * inv
+    if gamma is not None:
+        y = y * gamma
+    if beta is not None:
+        y = y + beta
+    out.copy_(y)
+    return out
+
+
+def batchnorm_backward(x, dy, gamma, save_mean, save_inv_std, dgamma=None, dbeta=None, dx=None, workspace=None):
+    """Gradient of the training-mode ``batchnorm_forward``: ``dbeta = sum dy``, ``dgamma = sum dy xhat``,
+    ``dx = gamma inv_std (dy - dbeta / R - xhat dgamma / R)``; each output may be None."""
+    R, C = x.shape
+    if x.is_cuda:
+        nv.require_f32_contig(x, dy, gamma, save_mean, save_inv_std, dgamma, dbeta, dx, workspace)
+        assert workspace is not None and workspace.numel() >= batchnorm_workspace_floats(R, C)
+        rc = nv.kernels().dtf_batchnorm_bwd(nv.ptr(x), nv.ptr(dy), nv.ptr(dx), R, C, nv.ptr(gamma), nv.ptr(save_mean),
+                                            nv.ptr(save_inv_std), nv.ptr(dgamma), nv.ptr(dbeta), nv.ptr(workspace),
+                                            nv.stream_ptr())
+        nv.check(rc, "dtf_batchnorm_bwd")
+        return dx
+    xhat = (x - save_mean) * save_inv_std
+    s0, s1 = dy.sum(dim=0), (dy * xhat).sum(dim=0)
+    if dbeta is not None:
+        dbeta.copy_(s0)
+    if dgamma is not None:
+        dgamma.copy_(s1)
+    if dx is not None:
+        a = save_inv_std if gamma is None else gamma * save_inv_std
+        dx.copy_(a * (dy - s0 / R - xhat * (s1 / R)))
+    return dx
+
+
 def softmax(z, out=None):
     """Row softmax of logits [M, C]."""
     if out is None:

@@ -315,6 +315,9 @@ class SyncReplicasStrategy:
         self.comm.broadcast(store.flat, 0)
         self.comm.broadcast(store.global_step, 0)
         self.comm.broadcast(store.beta_powers, 0)
+        for v in store.variables.values():           # moving statistics and the like (a restore gave them to the chief)
+            if not v.trainable and v.tensor is not None and v.tensor.dtype == torch.float32:
+                self.comm.broadcast(v.tensor, 0)
         if self.replicated or not self.buckets:
             for name in sorted(store.slots):
                 self.comm.broadcast(store.slots[name], 0)

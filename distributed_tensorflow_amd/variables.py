@@ -203,7 +203,10 @@ class VariableStore:
             v.grad = self.flat_grad[v.offset:v.offset + v.numel].view(v.shape)
         for v in self.variables.values():
             if not v.trainable:
-                v.tensor = torch.zeros(v.shape, dtype=v.dtype, device=self.device)
+                if v.dtype == torch.float32 and callable(v.initializer):
+                    v.tensor = v.initializer(v.shape, gen).to(self.device)      # e.g. a moving variance that starts at one
+                else:
+                    v.tensor = torch.zeros(v.shape, dtype=v.dtype, device=self.device)
         self.global_step = torch.zeros(1, dtype=torch.int64, device=self.device)
         self.beta_powers = torch.ones(2, dtype=torch.float32, device=self.device)
         self.finalized = True
