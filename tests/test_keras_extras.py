@@ -150,3 +150,21 @@ def test_fit_validation_split_holds_out_the_tail():
     import pytest
     with pytest.raises(ValueError):
         m.fit(x, y, epochs=1, batch_size=50, validation_split=1.5, verbose=0)
+
+
+def test_inspect_checkpoint_tool(tmp_path, capsys):
+    from distributed_tensorflow_amd.models import xor_mlp
+    from distributed_tensorflow_amd.saver import Saver
+    from distributed_tensorflow_amd.tools import inspect_checkpoint
+    m = xor_mlp()
+    m.compile(loss="mean_squared_error", optimizer="adam", device="cpu", seed=1)
+    Saver(m.store, m.optimizer).save(str(tmp_path / "model.ckpt"), global_step=7)
+    assert inspect_checkpoint.main([str(tmp_path)]) == 0                      # a directory: its latest checkpoint
+    out = capsys.readouterr().out
+    assert "model.ckpt-7" in out and "dense_1/kernel" in out and "(64, 128)" in out and "dense_3/bias/Adam_1" in out
+    assert "32768 bytes" in out
+    assert inspect_checkpoint.main([str(tmp_path / "model.ckpt-7"), "--tensor_name", "global_step"]) == 0
+    assert "int64" in capsys.readouterr().out
+    assert inspect_checkpoint.main([str(tmp_path / "model.ckpt-7"), "--tensor_name", "nope"]) == 1
+    (tmp_path / "empty").mkdir()
+    assert inspect_checkpoint.main([str(tmp_path / "empty")]) == 1
