@@ -199,3 +199,47 @@ def test_replicas_out_of_step_are_detected():
     for rank in (0, 1):
         assert res[rank][:2] == [False, True]                  # in step: the chief's decision reaches everybody
         assert "out of step" in res[rank][2] and "from 3 to 4" in res[rank][2]
+
+
+def _bn_worker(rank, world, port, out_q):
+    sys.path.insert(0, ROOT)
+    torch.set_num_threads(1)
+    from distributed_tensorflow_amd.data import mnist_like
+    from distributed_tensorflow_amd.layers import BatchNormalization, Dense
+    from distributed_tensorflow_amd.models import Sequential
+    from distributed_tensorflow_amd.parallel import Communicator, SyncReplicasStrategy, init_process_group
+    init_process_group("gloo", rank=rank, world_size=world, master_addr="127.0.0.1", master_port=port)
+    m = Sequential([Dense(16, input_dim=784), BatchNormalization(momentum=0.5), Dense(10, activation="softmax")])
+    strat = SyncReplicasStrategy(Communicator())
+    m.compile(loss="sparse_categorical_crossentropy", optimizer="adam", strategy=strat, device="cpu", seed=1 + rank)
+    mm = m.store.variables["batch_normalization_1/moving_mean"].tensor
+    if rank == 0:
+        mm.fill_(3.0)                      # as if the chief had restored a checkpoint
+    strat.broadcast_state(m)
+    received = mm.clone()
+    x, y = mnist_like(64, seed=rank)
+    for _ in range(3):
+        m.train_step(x, y)
+    out_q.put((rank, received.tolist(), mm.tolist(), m.store.flat.sum().item()))
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_batchnorm_under_synchronous_replicas():
+    """The non-trained moving statistics travel with the chief's state (after a restore they exist only there); during
+    training they stay each replica's own - its batches' statistics - while gamma / beta are averaged like any variable."""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bn_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1] == [3.0] * 16                 # broadcast from the chief
+    assert res[0][2] != res[1][2]                               # then local: different batches
+    assert abs(res[0][3] - res[1][3]) < 1e-4                    # the trained variables stay identical
