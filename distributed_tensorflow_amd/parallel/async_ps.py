@@ -618,6 +618,8 @@ class ParameterServerService:
                     name = p["name"] if not suffix else "%s/%s" % (p["name"], suffix)
                     w.add(name, t.reshape(p["shape"]), self.owner_index)
             if self.owner_index == 0:
+                for name, e in (req.get("extras") or {}).items():
+                    w.add(name, torch.tensor(e["values"], dtype=torch.float32).reshape(e["shape"]), 0)
                 w.add("global_step", torch.tensor(int(req["global_step"]), dtype=torch.int64), 0)
                 if req["optimizer"] == "Adam":
                     w.add("beta1_power", self.beta_powers[0], 0)
@@ -1460,8 +1462,13 @@ class AsyncPSStrategy:
         slots = getattr(model.optimizer, "slot_checkpoint_names", {})
         gs = self.global_step()
         base = self.cp0.add("%s/save_done/%s" % (self.ns, token), 0)
+        # variables that are not trained (moving statistics of batch normalisation) live on the workers; the chief's go
+        # into shard 0 with the request (they are a few channels' worth of numbers)
+        extras = {v.name: {"shape": list(v.shape), "values": v.tensor.detach().reshape(-1).cpu().tolist()}
+                  for v in model.store.variables.values()
+                  if not v.trainable and v.tensor is not None and v.tensor.dtype == torch.float32}
         self._post("save", {"prefix": prefix, "num_shards": self.num_owners, "slots": slots, "global_step": gs,
-                            "optimizer": model.optimizer.name, "token": token, "gather": self.gather})
+                            "optimizer": model.optimizer.name, "token": token, "gather": self.gather, "extras": extras})
         self._wait_counter("%s/save_done/%s" % (self.ns, token), base + self.num_owners)
         self._check_service()
         from ..saver import merge_shards

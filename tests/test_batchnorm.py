@@ -129,3 +129,56 @@ def test_training_improves_and_keras_namespace():
     m.fit(x, y, epochs=3, batch_size=100, verbose=0)
     l1, acc = m.evaluate(x, y, batch_size=500)[:2]
     assert l1 < 0.5 * l0 and acc > 0.8
+
+
+ASYNC_BN_WORKER = r'''
+import json, sys, torch
+sys.path.insert(0, %(root)r)
+torch.set_num_threads(1)
+from distributed_tensorflow_amd.cluster import ClusterSpec, Server
+from distributed_tensorflow_amd.data import mnist_like
+from distributed_tensorflow_amd.engine import ModelEngine
+from distributed_tensorflow_amd.layers import BatchNormalization, Dense
+from distributed_tensorflow_amd.models import Sequential
+from distributed_tensorflow_amd.parallel.async_ps import AsyncPSStrategy
+
+hosts, ckpt = sys.argv[1].split(","), sys.argv[2]
+srv = Server(ClusterSpec({"worker": hosts}), "worker", 0, config={"device": "cpu"})
+strat = AsyncPSStrategy(srv, max_staleness=0)
+m = Sequential([Dense(16, input_dim=784), BatchNormalization(momentum=0.5), Dense(10, activation="softmax")])
+m.compile(loss="sparse_categorical_crossentropy", optimizer="adam", strategy=strat, device="cpu", seed=2)
+eng = ModelEngine(m)
+eng.synchronize_state(True)
+x, y = mnist_like(64 * 4, seed=0)
+for i in range(4):
+    m.train_step(x[i * 64:(i + 1) * 64], y[i * 64:(i + 1) * 64])
+prefix = eng.save_checkpoint(eng.make_saver(), ckpt, 4)
+mm = m.store.variables["batch_normalization_1/moving_mean"].tensor.tolist()
+strat.worker_done()
+strat.shutdown_owners()
+print("RESULT " + json.dumps({"prefix": prefix, "moving_mean": mm}))
+'''
+
+
+def test_async_checkpoint_carries_the_chiefs_moving_statistics(tmp_path):
+    """Asynchronous parameter servers: the owners write the trained variables and their slots; the moving statistics
+    live on the workers, and the chief's are added to shard 0."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from distributed_tensorflow_amd.saver import BundleReader
+    from .test_example_cluster import _env, _ports
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "worker.py"
+    script.write_text(ASYNC_BN_WORKER % {"root": root})
+    ports = _ports(2)
+    out = subprocess.run([sys.executable, str(script), "127.0.0.1:%d" % ports[0], str(tmp_path / "model.ckpt")],
+                         env=_env({"DTF_RENDEZVOUS_PORT": str(ports[1])}), capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    with BundleReader(res["prefix"]) as r:
+        assert r.has_tensor("batch_normalization_1/gamma") and r.has_tensor("batch_normalization_1/gamma/Adam")
+        got = r.get_tensor("batch_normalization_1/moving_mean").tolist()
+        assert r.get_tensor("batch_normalization_1/moving_variance").shape == (16,)
+    assert got == pytest.approx(res["moving_mean"]) and any(abs(v) > 1e-4 for v in got)
