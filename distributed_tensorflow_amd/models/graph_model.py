@@ -155,6 +155,10 @@ class GraphModel(Sequential):
                             {0: None, 1: "relu", 2: "sigmoid", 3: "tanh"}[layer.act])
         if isinstance(layer, L.MaxPooling2D):
             return A.max_pool2d(x, layer.pool_size, layer.strides, layer.padding)
+        if isinstance(layer, L.BatchNormalization):
+            return A.batch_norm(x, self._leaf(layer.gamma) if layer.gamma is not None else None,
+                                self._leaf(layer.beta) if layer.beta is not None else None, layer.moving_mean.tensor,
+                                layer.moving_variance.tensor, layer.momentum, layer.epsilon, training)
         raise NotImplementedError("layer %s is not supported in a graph model" % type(layer).__name__)
 
     def _eval(self, node, env: dict, training: bool):

@@ -249,6 +249,53 @@ def max_pool2d(x, pool=(2, 2), strides=None, padding="valid"):
     return _MaxPoolFn.apply(x, pool, tuple(strides) if strides is not None else pool, str(padding).lower())
 
 
+class _BatchNormFn(torch.autograd.Function):
+    """Batch normalisation over the last axis (Keras semantics); ``moving_mean`` / ``moving_var`` are updated in place
+    while training.  Gradients flow to ``x``, ``gamma`` and ``beta``."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, moving_mean, moving_var, momentum, eps, training):
+        x = _c(x)
+        C = x.shape[-1]
+        x2 = x.reshape(-1, C)
+        R = x2.shape[0]
+        y = torch.empty_like(x2)
+        mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        inv = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws = torch.empty(F.batchnorm_workspace_floats(R, C), dtype=torch.float32, device=x.device) if x.is_cuda else None
+        F.batchnorm_forward(x2, _c(gamma), _c(beta), moving_mean, moving_var, momentum, eps, training, y, mean, inv, ws)
+        if not training:
+            inv = 1.0 / torch.sqrt(moving_var + eps)
+            mean = moving_mean.clone()
+        ctx.save_for_backward(x2, gamma if gamma is not None else torch.empty(0), mean, inv)
+        ctx.cfg = (tuple(x.shape), gamma is not None, beta is not None, bool(training), ws)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, gamma, mean, inv = ctx.saved_tensors
+        shape, has_gamma, has_beta, training, ws = ctx.cfg
+        dy2 = _c(dy).reshape(x2.shape)
+        g = _c(gamma) if has_gamma else None
+        if not training:       # the affine map of the moving statistics
+            xhat = (x2 - mean) * inv
+            dx = dy2 * (inv if g is None else g * inv)
+            return (dx.view(shape), (dy2 * xhat).sum(0) if has_gamma else None, dy2.sum(0) if has_beta else None,
+                    None, None, None, None, None)
+        C = x2.shape[1]
+        dgamma = torch.empty(C, dtype=torch.float32, device=x2.device)
+        dbeta = torch.empty(C, dtype=torch.float32, device=x2.device)
+        dx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
+        F.batchnorm_backward(x2, dy2, g, mean, inv, dgamma, dbeta, dx, ws)
+        return (dx.view(shape) if dx is not None else None, dgamma if has_gamma else None, dbeta if has_beta else None,
+                None, None, None, None, None)
+
+
+def batch_norm(x, gamma, beta, moving_mean, moving_var, momentum: float = 0.99, eps: float = 1e-3, training: bool = True):
+    """Differentiable batch normalisation over the last axis of ``x`` (``gamma`` / ``beta`` may be None)."""
+    return _BatchNormFn.apply(x, gamma, beta, moving_mean, moving_var, float(momentum), float(eps), bool(training))
+
+
 # ----------------------------------------------------------------------------------------------- torch.nn modules
 class Dense(torch.nn.Module):
     """``torch.nn.Module`` whose forward and backward are the fused HIP dense kernels (Glorot-uniform kernel
@@ -289,3 +336,20 @@ class MaxPooling2D(torch.nn.Module):
 
     def forward(self, x):
         return max_pool2d(x, self.pool_size, self.strides, self.padding)
+
+
+class BatchNormalization(torch.nn.Module):
+    """Keras-style batch normalisation over the last axis on the HIP kernels (``moving_*`` follow the batch statistics
+    with ``momentum`` while ``self.training``)."""
+
+    def __init__(self, channels: int, momentum: float = 0.99, epsilon: float = 1e-3, center: bool = True, scale: bool = True):
+        super().__init__()
+        self.gamma = torch.nn.Parameter(torch.ones(channels)) if scale else None
+        self.beta = torch.nn.Parameter(torch.zeros(channels)) if center else None
+        self.register_buffer("moving_mean", torch.zeros(channels))
+        self.register_buffer("moving_variance", torch.ones(channels))
+        self.momentum, self.epsilon = float(momentum), float(epsilon)
+
+    def forward(self, x):
+        return batch_norm(x, self.gamma, self.beta, self.moving_mean, self.moving_variance, self.momentum, self.epsilon,
+                          self.training)

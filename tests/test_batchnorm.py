@@ -182,3 +182,60 @@ def test_async_checkpoint_carries_the_chiefs_moving_statistics(tmp_path):
         got = r.get_tensor("batch_normalization_1/moving_mean").tolist()
         assert r.get_tensor("batch_normalization_1/moving_variance").shape == (16,)
     assert got == pytest.approx(res["moving_mean"]) and any(abs(v) > 1e-4 for v in got)
+
+
+def check_autograd_function(device):
+    from distributed_tensorflow_amd.ops import autograd as A
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(6, 5, 5, 8, generator=g)
+    gamma, beta = torch.rand(8, generator=g) + 0.5, torch.randn(8, generator=g)
+    w = torch.randn(6, 5, 5, 8, generator=g)
+    for training in (True, False):
+        mm, mv = torch.zeros(8) + 0.1, torch.ones(8) * 1.5
+        xa, ga, ba = (t.clone().to(device).requires_grad_(True) for t in (x, gamma, beta))
+        mma, mva = mm.clone().to(device), mv.clone().to(device)
+        (A.batch_norm(xa, ga, ba, mma, mva, 0.9, 1e-3, training) * w.to(device)).sum().backward()
+        xr, gr, br = (t.clone().double().requires_grad_(True) for t in (x, gamma, beta))
+        mmr, mvr = mm.double().clone(), mv.double().clone()
+        y = torch.nn.functional.batch_norm(xr.permute(0, 3, 1, 2), mmr, mvr, gr, br, training, 0.1, 1e-3).permute(0, 2, 3, 1)
+        (y * w.double()).sum().backward()
+        torch.testing.assert_close(xa.grad.cpu().double(), xr.grad, rtol=2e-3, atol=2e-5)
+        torch.testing.assert_close(ga.grad.cpu().double(), gr.grad, rtol=1e-3, atol=1e-4)
+        torch.testing.assert_close(ba.grad.cpu().double(), br.grad, rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(mma.cpu().double(), mmr, rtol=1e-5, atol=1e-6)      # (PyTorch's running variance is the
+        # unbiased one, Keras' the biased one: only the mean is compared)
+
+
+def test_autograd_function_cpu():
+    check_autograd_function("cpu")
+
+
+@pytest.mark.gpu
+def test_autograd_function_gpu(gpu_device):
+    check_autograd_function(gpu_device)
+
+
+def test_graph_model_with_a_skip_connection_uses_it():
+    """A residual block with batch normalisation in the graph front end (a DAG, so it runs on the autograd functions)."""
+    from distributed_tensorflow_amd import compat as tf
+    tf.reset_default_graph()
+    K = tf.keras.backend
+    x = tf.placeholder(tf.float32, shape=(None, 16))
+    y = tf.placeholder(tf.float32, shape=(None, 16))
+    h = tf.keras.layers.Dense(16, activation="relu")(x)
+    h = tf.keras.layers.BatchNormalization(momentum=0.8)(h)
+    out = tf.keras.layers.Dense(16, activation="sigmoid")(h + x)
+    loss = tf.reduce_mean(tf.keras.losses.mean_squared_error(y, out))
+    train = tf.train.AdamOptimizer(0.01).minimize(loss)
+    g = torch.Generator().manual_seed(2)
+    bx = torch.rand(64, 16, generator=g).numpy()
+    by = (torch.rand(64, 16, generator=g) > 0.5).float().numpy()
+    with tf.train.MonitoredTrainingSession() as sess:
+        eng = tf.get_default_graph().engine()
+        assert eng.dag
+        first = sess.run(loss, {x: bx, y: by, K.learning_phase(): 1})
+        for _ in range(60):
+            sess.run(train, {x: bx, y: by, K.learning_phase(): 1})
+        last = sess.run(loss, {x: bx, y: by, K.learning_phase(): 0})       # inference mode: the moving statistics
+        mv = eng.model.store.variables["batch_normalization_1/moving_variance"].tensor
+    assert last < first and not torch.allclose(mv.cpu(), torch.ones(16))
