@@ -16,6 +16,8 @@
 // tf.train.AdagradOptimizer, Keras 'rmsprop' / 'adagrad'); both keep a running sum of squared gradients per element:
 //     RMSProp   a <- rho a + (1 - rho) g^2     u = lr g / D(a)     mom <- momentum mom + u ; var <- var - mom
 //     Adagrad   a <- a + g^2                   var <- var - lr g / D(a)
+//     Adadelta  a <- rho a + (1 - rho) g^2     u = g sqrt(d + eps) / sqrt(a + eps);  var <- var - lr u;
+//               d <- rho d + (1 - rho) u^2     (TensorFlow's ApplyAdadelta and Keras' Adadelta agree)
 // D(a) = sqrt(a + eps) in TensorFlow's kernels and sqrt(a) + eps in Keras' Python formulas: `eps_inside` selects.
 #include "common.h"
 
@@ -131,7 +133,8 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ var, float
     advance_if_last(adv);
 }
 
-// RULE 0: RMSProp (mom may be null: no momentum slot), RULE 1: Adagrad (rho, momentum, mom unused).
+// RULE 0: RMSProp (mom may be null: no momentum slot), RULE 1: Adagrad (rho, momentum, mom unused), RULE 2: Adadelta
+// (mom holds the accumulated squared updates d).
 template <int RULE>
 __global__ __launch_bounds__(256) void accum_rule_kernel(float* __restrict__ var, float* __restrict__ acc,
                                                          float* __restrict__ mom, const float* __restrict__ g,
@@ -143,6 +146,13 @@ __global__ __launch_bounds__(256) void accum_rule_kernel(float* __restrict__ var
     const float omr = 1.0f - rho;
     auto one = [&](float gj, float& a, float& mo, float& w) {
         gj *= grad_scale;
+        if (RULE == 2) {
+            a = rho * a + omr * gj * gj;
+            const float u = gj * sqrtf(mo + eps) / sqrtf(a + eps);
+            mo = rho * mo + omr * u * u;
+            w -= lr * u;
+            return;
+        }
         a = RULE == 0 ? rho * a + omr * gj * gj : a + gj * gj;
         const float d = eps_inside ? sqrtf(a + eps) : sqrtf(a) + eps;
         float u = lr * gj / d;
@@ -158,7 +168,7 @@ __global__ __launch_bounds__(256) void accum_rule_kernel(float* __restrict__ var
     const f32x4* g4 = reinterpret_cast<const f32x4*>(g);
     for (long long i = tid; i < n4; i += stride) {
         f32x4 gg = g4[i], aa = a4[i], w = var4[i], mm = {0.f, 0.f, 0.f, 0.f};
-        if (RULE == 0 && mom) mm = mo4[i];
+        if (RULE != 1 && mom) mm = mo4[i];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float a = aa[j], mo = mm[j], wj = w[j];
@@ -168,14 +178,14 @@ __global__ __launch_bounds__(256) void accum_rule_kernel(float* __restrict__ var
             w[j] = wj;
         }
         a4[i] = aa;
-        if (RULE == 0 && mom) mo4[i] = mm;
+        if (RULE != 1 && mom) mo4[i] = mm;
         var4[i] = w;
     }
     for (long long i = (n4 << 2) + tid; i < n; i += stride) {
-        float a = acc[i], w = var[i], mo = (RULE == 0 && mom) ? mom[i] : 0.f;
+        float a = acc[i], w = var[i], mo = (RULE != 1 && mom) ? mom[i] : 0.f;
         one(g[i], a, mo, w);
         acc[i] = a;
-        if (RULE == 0 && mom) mom[i] = mo;
+        if (RULE != 1 && mom) mom[i] = mo;
         var[i] = w;
     }
     advance_if_last(adv);
@@ -245,6 +255,21 @@ DTF_API int dtf_rmsprop_apply(float* var, float* ms, float* mom, const float* g,
         return -2;
     hipLaunchKernelGGL(accum_rule_kernel<0>, dim3(flat_grid(n)), dim3(256), 0, stream, var, ms, mom, g, n, lr, rho,
                        momentum, eps, eps_inside, grad_scale, adv);
+    DTF_CHECK_LAUNCH();
+    return 0;
+}
+
+DTF_API int dtf_adadelta_apply(float* var, float* acc, float* acc_update, const float* g, long long n, float lr, float rho,
+                               float eps, float grad_scale, long long* advance_step, unsigned int* ticket, hipStream_t stream) {
+    if (n <= 0) return 0;
+    if (advance_step && !ticket) return -3;
+    if (!acc_update) return -3;
+    const Advance adv = {advance_step, nullptr, ticket, 0.f, 0.f};
+    if ((reinterpret_cast<uintptr_t>(var) | reinterpret_cast<uintptr_t>(acc) | reinterpret_cast<uintptr_t>(acc_update) |
+         reinterpret_cast<uintptr_t>(g)) & 15)
+        return -2;
+    hipLaunchKernelGGL(accum_rule_kernel<2>, dim3(flat_grid(n)), dim3(256), 0, stream, var, acc, acc_update, g, n, lr, rho,
+                       0.f, eps, 1, grad_scale, adv);
     DTF_CHECK_LAUNCH();
     return 0;
 }

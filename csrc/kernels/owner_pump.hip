@@ -44,6 +44,9 @@ extern "C" int dtf_adam_apply(float* var, float* m, float* v, const float* g, lo
 extern "C" int dtf_rmsprop_apply(float* var, float* ms, float* mom, const float* g, long long n, float lr, float rho,
                                  float momentum, float eps, int eps_inside, float grad_scale, long long* advance_step,
                                  unsigned int* ticket, hipStream_t stream);
+extern "C" int dtf_adadelta_apply(float* var, float* acc, float* acc_update, const float* g, long long n, float lr, float rho,
+                                  float eps, float grad_scale, long long* advance_step, unsigned int* ticket,
+                                  hipStream_t stream);
 extern "C" int dtf_adagrad_apply(float* var, float* acc, const float* g, long long n, float lr, float eps, int eps_inside,
                                  float grad_scale, long long* advance_step, unsigned int* ticket, hipStream_t stream);
 extern "C" int dtf_sgd_apply(float* var, float* mom, const float* g, long long n, float lr, float momentum,
@@ -77,7 +80,7 @@ static_assert(offsetof(Ctl, lane) == 128, "control block layout is shared with t
 
 struct Config {
     int on_gpu, owner, workers, depth;
-    int optimizer;                              // 0 Adam, 1 SGD (momentum slot optional), 2 RMSProp, 3 Adagrad
+    int optimizer;                              // 0 Adam, 1 SGD (momentum slot optional), 2 RMSProp, 3 Adagrad, 4 Adadelta
     int pad;
     long long n;                                // elements of this owner's shard
     long long slot_stride;                      // elements between inbox slots
@@ -234,6 +237,16 @@ void cpu_apply(const Config& c, const float* g) {
             }
             c.var[i] -= c.lr * gi;
         }
+    } else if (c.optimizer == 4) {
+        // Adadelta: m = accumulated squared gradients, v = accumulated squared updates, b1 = rho
+        for (long long i = 0; i < n; ++i) {
+            const float gi = g[i];
+            const float a = c.b1 * c.m[i] + (1.0f - c.b1) * gi * gi;
+            const float u = gi * std::sqrt(c.v[i] + c.eps) / std::sqrt(a + c.eps);
+            c.m[i] = a;
+            c.v[i] = c.b1 * c.v[i] + (1.0f - c.b1) * u * u;
+            c.var[i] -= c.lr * u;
+        }
     } else {
         // RMSProp (2: m = mean square, v = momentum accumulator or null, b1 = rho) and Adagrad (3: m = accumulator);
         // b2 != 0: epsilon inside the root (TensorFlow's kernels), else outside (Keras' formulas) - as optim.hip
@@ -265,6 +278,8 @@ int gpu_apply(Pump* p, const float* g) {
     if (c.optimizer == 2)
         return dtf_rmsprop_apply(c.var, c.m, c.momentum > 0.0f ? c.v : nullptr, g, c.n, c.lr, c.b1, c.momentum, c.eps,
                                  c.b2 != 0.0f ? 1 : 0, 1.0f, c.step, c.ticket, p->stream);
+    if (c.optimizer == 4)
+        return dtf_adadelta_apply(c.var, c.m, c.v, g, c.n, c.lr, c.b1, c.eps, 1.0f, c.step, c.ticket, p->stream);
     return dtf_adagrad_apply(c.var, c.m, g, c.n, c.lr, c.eps, c.b2 != 0.0f ? 1 : 0, 1.0f, c.step, c.ticket, p->stream);
 }
 

@@ -779,6 +779,11 @@ class AdagradOptimizer(_GraphOptimizer):
         super().__init__(_optimizers.Adagrad(lr=learning_rate, initial_accumulator_value=initial_accumulator_value))
 
 
+class AdadeltaOptimizer(_GraphOptimizer):
+    def __init__(self, learning_rate=0.001, rho=0.95, epsilon=1e-8, use_locking=False, name="Adadelta"):
+        super().__init__(_optimizers.Adadelta(lr=learning_rate, rho=rho, epsilon=epsilon))
+
+
 class SyncReplicasOptimizer(_GraphOptimizer):
     """``tf.train.SyncReplicasOptimizer(opt, replicas_to_aggregate=N)``: gradients of all workers are averaged
     and applied once per global step (reduce-scatter / sharded apply / all-gather)."""
@@ -814,7 +819,7 @@ summary = types.SimpleNamespace(scalar=_summary.scalar, merge_all=_summary.merge
 
 train = types.SimpleNamespace(
     AdamOptimizer=AdamOptimizer, GradientDescentOptimizer=GradientDescentOptimizer, MomentumOptimizer=MomentumOptimizer,
-    RMSPropOptimizer=RMSPropOptimizer, AdagradOptimizer=AdagradOptimizer,
+    RMSPropOptimizer=RMSPropOptimizer, AdagradOptimizer=AdagradOptimizer, AdadeltaOptimizer=AdadeltaOptimizer,
     SyncReplicasOptimizer=SyncReplicasOptimizer, ClusterSpec=_cluster.ClusterSpec, Server=_cluster.Server,
     replica_device_setter=_cluster.replica_device_setter, StopAtStepHook=_session.StopAtStepHook,
     StepCounterHook=_session.StepCounterHook, SummarySaverHook=_session.SummarySaverHook,
@@ -907,5 +912,6 @@ keras = types.SimpleNamespace(
                                     History=_callbacks.History),
     optimizers=types.SimpleNamespace(Adam=_optimizers.Adam, SGD=_optimizers.SGD,
                                      RMSprop=lambda **kw: _optimizers.RMSProp(keras=True, **kw),
-                                     Adagrad=lambda **kw: _optimizers.Adagrad(keras=True, **kw)),
+                                     Adagrad=lambda **kw: _optimizers.Adagrad(keras=True, **kw),
+                                     Adadelta=lambda **kw: _optimizers.Adadelta(**dict({"lr": 1.0}, **kw))),
 )

@@ -323,7 +323,7 @@ def model_nodes(model, worker_device: str = "", variable_device=None, loss_name:
         updates = []
         for v in var_names:
             slots = {"Adam": ["Adam", "Adam_1"], "SGD": [], "RMSProp": ["RMSProp", "RMSProp_1"],
-                     "Adagrad": ["Adagrad"]}.get(opt, [])
+                     "Adagrad": ["Adagrad"], "Adadelta": ["Adadelta", "Adadelta_1"]}.get(opt, [])
             for s in slots:
                 nodes.append(Node("%s/%s" % (v, s), "VariableV2", device=vdev(v), dtype=DT_FLOAT))
             up = "%s/update_%s/Apply%s" % (opt, v, {"SGD": "GradientDescent"}.get(opt, opt))

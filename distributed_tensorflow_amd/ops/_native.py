@@ -73,6 +73,7 @@ def kernels():
         "dtf_sgd_apply": [c_p, c_p, c_p, c_ll, c_f, c_f, c_f, c_p, c_p, c_p],
         "dtf_rmsprop_apply": [c_p, c_p, c_p, c_p, c_ll, c_f, c_f, c_f, c_f, c_i, c_f, c_p, c_p, c_p],
         "dtf_adagrad_apply": [c_p, c_p, c_p, c_ll, c_f, c_f, c_i, c_f, c_p, c_p, c_p],
+        "dtf_adadelta_apply": [c_p, c_p, c_p, c_p, c_ll, c_f, c_f, c_f, c_f, c_p, c_p, c_p],
         "dtf_step_advance": [c_p, c_p, c_f, c_f, c_p],
         "dtf_act_grad": [c_p, c_p, c_p, c_ll, c_i, c_f, c_p],
         "dtf_dropout": [c_p, c_p, c_ll, c_f, c_u32, c_p, c_p],

@@ -561,6 +561,28 @@ def adagrad_apply(var, acc, grad, lr, eps=0.0, eps_inside=True, grad_scale=1.0, 
     return var
 
 
+def adadelta_apply(var, acc, acc_update, grad, lr=1.0, rho=0.95, eps=1e-8, grad_scale=1.0, advance=None):
+    """Adadelta on flat fp32 ranges: ``acc <- rho acc + (1-rho) g^2``, ``u = g sqrt(acc_update + eps) / sqrt(acc + eps)``,
+    ``var -= lr u``, ``acc_update <- rho acc_update + (1-rho) u^2`` (TensorFlow's ApplyAdadelta = Keras' Adadelta)."""
+    n = var.numel()
+    assert acc.numel() == n and acc_update.numel() == n and grad.numel() == n
+    if var.is_cuda:
+        nv.require_f32_contig(var, acc, acc_update, grad)
+        rc = nv.kernels().dtf_adadelta_apply(nv.ptr(var), nv.ptr(acc), nv.ptr(acc_update), nv.ptr(grad), n, float(lr), float(rho),
+                                             float(eps), float(grad_scale), nv.ptr(advance),
+                                             nv.ptr(_ticket(var.device)) if advance is not None else 0, nv.stream_ptr())
+        nv.check(rc, "dtf_adadelta_apply")
+        return var
+    g = grad * grad_scale
+    acc.mul_(rho).addcmul_(g, g, value=1.0 - rho)
+    u = g * (acc_update + eps).sqrt() / (acc + eps).sqrt()
+    acc_update.mul_(rho).addcmul_(u, u, value=1.0 - rho)
+    var.sub_(lr * u)
+    if advance is not None:
+        step_advance(advance)
+    return var
+
+
 def step_advance(step, beta_powers=None, beta1=0.9, beta2=0.999):
     """``global_step += 1``; TF's non-slot ``beta1_power``/``beta2_power`` variables ``*= beta``."""
     if step.is_cuda:

@@ -223,9 +223,42 @@ class Adagrad(Optimizer):
                         not self.keras, grad_scale, advance=store.global_step)
 
 
+class Adadelta(Optimizer):
+    """``tf.train.AdadeltaOptimizer(learning_rate=0.001, rho=0.95, epsilon=1e-8)`` (slots ``<var>/Adadelta`` and
+    ``<var>/Adadelta_1``); ``get('adadelta')`` is Keras' ``Adadelta(lr=1.0, rho=0.95, epsilon=1e-8)`` - one formula,
+    different default rates."""
+
+    slot_checkpoint_names = {"accum": "Adadelta", "accum_update": "Adadelta_1"}
+    name = "Adadelta"
+
+    def __init__(self, lr: float = 0.001, rho: float = 0.95, epsilon: float = 1e-8, learning_rate: Optional[float] = None):
+        self.lr = float(learning_rate if learning_rate is not None else lr)
+        self.rho, self.epsilon = float(rho), float(epsilon)
+
+    def describe(self):
+        return {"name": "Adadelta", "args": {"lr": self.lr, "rho": self.rho, "epsilon": self.epsilon}}
+
+    def pump_parameters(self):
+        return 4, self.lr, self.rho, 0.0, self.epsilon, 0.0
+
+    def create_slots(self, store):
+        store.slot("accum")
+        store.slot("accum_update")
+
+    def apply(self, store, begin=0, end=None, grad_scale=1.0, grad=None, step=None):
+        end = store.flat_len if end is None else end
+        g = store.flat_grad if grad is None else grad
+        F.adadelta_apply(store.flat[begin:end], store.slot("accum")[begin:end], store.slot("accum_update")[begin:end],
+                         g[begin:end], self.lr, self.rho, self.epsilon, grad_scale)
+
+    def apply_and_finish(self, store, grad_scale=1.0):
+        F.adadelta_apply(store.flat, store.slot("accum"), store.slot("accum_update"), store.flat_grad, self.lr, self.rho,
+                         self.epsilon, grad_scale, advance=store.global_step)
+
+
 def from_description(desc: dict) -> Optimizer:
     """Inverse of ``Optimizer.describe`` (how a parameter-server task learns which rule its shard is updated by)."""
-    classes = {"Adam": Adam, "SGD": SGD, "RMSProp": RMSProp, "Adagrad": Adagrad}
+    classes = {"Adam": Adam, "SGD": SGD, "RMSProp": RMSProp, "Adagrad": Adagrad, "Adadelta": Adadelta}
     return classes[desc["name"]](**desc["args"])
 
 
@@ -244,6 +277,7 @@ GradientDescentOptimizer = SGD
 
 RMSPropOptimizer = RMSProp
 AdagradOptimizer = Adagrad
+AdadeltaOptimizer = Adadelta
 
 
 def MomentumOptimizer(learning_rate, momentum):
@@ -251,7 +285,8 @@ def MomentumOptimizer(learning_rate, momentum):
 
 
 # the Keras strings build the Keras forms
-_REGISTRY = {"adam": Adam, "sgd": SGD, "rmsprop": lambda: RMSProp(keras=True), "adagrad": lambda: Adagrad(keras=True)}
+_REGISTRY = {"adam": Adam, "sgd": SGD, "rmsprop": lambda: RMSProp(keras=True), "adagrad": lambda: Adagrad(keras=True),
+             "adadelta": lambda: Adadelta(lr=1.0)}
 
 
 def get(spec) -> Optimizer:

@@ -168,3 +168,43 @@ def test_inspect_checkpoint_tool(tmp_path, capsys):
     assert inspect_checkpoint.main([str(tmp_path / "model.ckpt-7"), "--tensor_name", "nope"]) == 1
     (tmp_path / "empty").mkdir()
     assert inspect_checkpoint.main([str(tmp_path / "empty")]) == 1
+
+
+def _keras_mnist_cnn(device):
+    """The architecture and compile line of Keras' own mnist_cnn example."""
+    from distributed_tensorflow_amd.layers import Conv2D, Dense, Dropout, Flatten, MaxPooling2D
+    from distributed_tensorflow_amd.models import Sequential
+    m = Sequential([Conv2D(32, (3, 3), activation="relu", input_shape=(28, 28, 1)), Conv2D(64, (3, 3), activation="relu"),
+                    MaxPooling2D((2, 2)), Dropout(0.25), Flatten(), Dense(128, activation="relu"), Dropout(0.5),
+                    Dense(10, activation="softmax")])
+    m.compile(loss="categorical_crossentropy", optimizer="adadelta", metrics=["accuracy"], device=device, seed=3)
+    return m
+
+
+def _fit_keras_mnist_cnn(device, n, epochs):
+    import torch
+    from distributed_tensorflow_amd.data import mnist_like
+    x, y = mnist_like(n, seed=4)
+    x = x.view(n, 28, 28, 1)
+    y1 = torch.nn.functional.one_hot(y, 10).float()
+    m = _keras_mnist_cnn(device)
+    l0 = m.evaluate(x, y1, batch_size=n // 2)[0]
+    m.fit(x, y1, epochs=epochs, batch_size=64, verbose=0)
+    l1, acc = m.evaluate(x, y1, batch_size=n // 2)[:2]
+    return l0, l1, acc, m
+
+
+def test_keras_mnist_cnn_example_runs_as_written():
+    l0, l1, acc, m = _fit_keras_mnist_cnn("cpu", 256, 3)
+    assert m.optimizer.name == "Adadelta" and m.optimizer.lr == 1.0
+    assert l1 < 0.9 * l0 and acc > 0.3            # twelve steps: it has started to learn
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_keras_mnist_cnn_example_on_the_gpu(gpu_device):
+    l0, l1, acc, m = _fit_keras_mnist_cnn(gpu_device, 2048, 3)
+    print("keras mnist_cnn on the GPU:", l0, l1, acc)
+    assert l1 < 0.5 * l0 and acc > 0.8

@@ -221,6 +221,15 @@ def test_rmsprop_and_adagrad_kernels(gpu_device, inside):
     torch.testing.assert_close(v.cpu(), r, rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(acc.cpu(), racc, rtol=1e-6, atol=1e-7)
     assert step.item() == 12
+    v, a, u = var.to(gpu_device), torch.zeros(n, device=gpu_device), torch.zeros(n, device=gpu_device)
+    r, ra, ru = var.clone(), torch.zeros(n), torch.zeros(n)
+    for t in range(4):
+        g = torch.randn(n, generator=g0)
+        F.adadelta_apply(v, a, u, g.to(gpu_device), 1.0, 0.95, 1e-8, advance=step)
+        F.adadelta_apply(r, ra, ru, g, 1.0, 0.95, 1e-8)
+    torch.testing.assert_close(v.cpu(), r, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(u.cpu(), ru, rtol=1e-4, atol=1e-9)
+    assert step.item() == 16
 
 
 def test_xor_generator_matches_cpu(gpu_device):

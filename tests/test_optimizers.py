@@ -62,7 +62,21 @@ def test_adagrad_forms():
     torch.testing.assert_close(var.double(), ref, rtol=1e-5, atol=1e-6)
 
 
+def test_adadelta_matches_torch():
+    n = 733
+    p = torch.nn.Parameter(_rand(n, 5))
+    opt = torch.optim.Adadelta([p], lr=1.0, rho=0.95, eps=1e-8)
+    var, acc, upd = p.detach().clone(), torch.zeros(n), torch.zeros(n)
+    for t in range(5):
+        g = _rand(n, 50 + t)
+        p.grad = g.clone()
+        opt.step()
+        F.adadelta_apply(var, acc, upd, g, 1.0, 0.95, 1e-8)
+    torch.testing.assert_close(var, p.detach(), rtol=1e-5, atol=1e-6)
+
+
 @pytest.mark.parametrize("spec,slots", [
+    ("adadelta", {"Adadelta": 0.0, "Adadelta_1": 0.0}),
     ("rmsprop", {"RMSProp": 0.0}),
     (optimizers.RMSProp(lr=1e-3, momentum=0.9), {"RMSProp": 1.0, "RMSProp_1": 0.0}),
     ("adagrad", {"Adagrad": 0.0}),
@@ -100,12 +114,12 @@ def test_training_and_checkpoint_names(tmp_path, spec, slots):
 
 def test_describe_round_trip_and_pump_codes():
     for opt in (optimizers.Adam(lr=2e-3), optimizers.SGD(lr=0.1, momentum=0.8), optimizers.RMSProp(momentum=0.5),
-                optimizers.RMSProp(keras=True), optimizers.Adagrad(), optimizers.Adagrad(keras=True)):
+                optimizers.RMSProp(keras=True), optimizers.Adagrad(), optimizers.Adagrad(keras=True), optimizers.Adadelta(lr=0.5)):
         back = optimizers.from_description(opt.describe())
         assert type(back) is type(opt) and back.describe() == opt.describe()
         assert back.pump_parameters() == opt.pump_parameters() and back.slot_order == opt.slot_order
-    assert [o.pump_parameters()[0] for o in (optimizers.Adam(), optimizers.SGD(), optimizers.RMSProp(), optimizers.Adagrad())] \
-        == [0, 1, 2, 3]
+    assert [o.pump_parameters()[0] for o in (optimizers.Adam(), optimizers.SGD(), optimizers.RMSProp(), optimizers.Adagrad(),
+                                             optimizers.Adadelta())] == [0, 1, 2, 3, 4]
 
 
 def test_tf_namespace_builds_them():
@@ -114,6 +128,9 @@ def test_tf_namespace_builds_them():
     assert isinstance(a, optimizers.RMSProp) and a.slot_order == ["rms", "momentum"] and a.epsilon == 1e-10 and not a.keras
     b = tf.train.AdagradOptimizer(0.1).optimizer
     assert isinstance(b, optimizers.Adagrad) and b.slot_initial("accumulator") == pytest.approx(0.1)
+    c = tf.train.AdadeltaOptimizer().optimizer
+    assert isinstance(c, optimizers.Adadelta) and c.lr == 0.001 and optimizers.get("adadelta").lr == 1.0
+    assert tf.keras.optimizers.Adadelta().lr == 1.0
     with pytest.raises(NotImplementedError):
         tf.train.RMSPropOptimizer(0.01, centered=True)
 
@@ -150,14 +167,15 @@ print("RESULT " + json.dumps({"index": index, "global_step": gs, "flat": m.store
 
 
 @pytest.mark.parametrize("opt", [optimizers.RMSProp(lr=2e-3, momentum=0.9), optimizers.Adagrad(lr=0.05),
-                                 optimizers.RMSProp(keras=True)], ids=["rmsprop-momentum", "adagrad", "rmsprop-keras"])
+                                 optimizers.RMSProp(keras=True), optimizers.Adadelta(lr=1.0)],
+                         ids=["rmsprop-momentum", "adagrad", "rmsprop-keras", "adadelta"])
 def test_parameter_server_owner_applies_the_rule(tmp_path, opt):
     _owner_applies_the_rule(tmp_path, opt, "cpu")
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("opt", [optimizers.RMSProp(lr=2e-3, momentum=0.9), optimizers.Adagrad(lr=0.05)],
-                         ids=["rmsprop-momentum", "adagrad"])
+@pytest.mark.parametrize("opt", [optimizers.RMSProp(lr=2e-3, momentum=0.9), optimizers.Adagrad(lr=0.05),
+                                 optimizers.Adadelta(lr=1.0)], ids=["rmsprop-momentum", "adagrad", "adadelta"])
 def test_parameter_server_owner_applies_the_rule_on_the_gpu(tmp_path, opt, gpu_device):
     _owner_applies_the_rule(tmp_path, opt, str(gpu_device))
 
