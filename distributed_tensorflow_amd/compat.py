@@ -286,6 +286,27 @@ def add(x, y, name=None): return Tensor("add", [x, y], name=name)
 def _bias_add(value, bias, name=None): return Tensor("bias_add", [value, bias], name=name or "BiasAdd")
 def _relu(x, name=None): return Tensor("relu", [x], name=name or "Relu")
 def _softmax(x, name=None, **_): return Tensor("softmax", [x], name=name or "Softmax")
+def _nhwc4(v, what):
+    v = list(v) if isinstance(v, (list, tuple)) else [1, int(v), int(v), 1]
+    if len(v) == 2:
+        v = [1, v[0], v[1], 1]
+    if len(v) != 4 or v[0] != 1 or v[3] != 1:
+        raise NotImplementedError("%s must be [1, h, w, 1] (NHWC)" % what)
+    return int(v[1]), int(v[2])
+def _nn_conv2d(input, filter, strides, padding, data_format="NHWC", name=None, **_):
+    """``tf.nn.conv2d`` on an NHWC tensor with a ``[kh, kw, cin, cout]`` filter variable."""
+    if data_format != "NHWC":
+        raise NotImplementedError("tf.nn.conv2d: NHWC only")
+    return Tensor("conv2d", [input, filter], {"strides": _nhwc4(strides, "strides"), "padding": str(padding).lower()},
+                  name=name or "Conv2D")
+def _nn_max_pool(value, ksize, strides, padding, data_format="NHWC", name=None, **_):
+    if data_format != "NHWC":
+        raise NotImplementedError("tf.nn.max_pool: NHWC only")
+    return Tensor("max_pool", [value], {"ksize": _nhwc4(ksize, "ksize"), "strides": _nhwc4(strides, "strides"),
+                                        "padding": str(padding).lower()}, name=name or "MaxPool")
+def reshape(tensor, shape, name=None):
+    """``tf.reshape`` with a static shape (one -1 allowed, typically the batch dimension)."""
+    return Tensor("reshape", [tensor], {"shape": tuple(int(s) for s in shape)}, name=name or "Reshape")
 def _nn_dropout(x, keep_prob, noise_shape=None, seed=None, name=None):
     if not isinstance(keep_prob, (int, float)):
         raise NotImplementedError("tf.nn.dropout: keep_prob must be a Python number here (training / evaluation is "
@@ -340,6 +361,7 @@ def _eval_generic(node, env: Dict[Tensor, torch.Tensor], engine: "GraphEngine", 
     elif op == "matmul": out = ins[0] @ ins[1]
     elif op == "bias_add": out = ins[0] + ins[1]
     elif op == "nn_dropout": out = ins[0]          # evaluation outside the training path: identity
+    elif op == "reshape": out = ins[0].reshape(node.attrs["shape"])
     elif op == "argmax": out = ins[0].argmax(dim=node.attrs["axis"] if node.attrs["axis"] is not None else 0)
     elif op == "reduce_mean":
         out = ins[0].float().mean() if node.attrs["axis"] is None else ins[0].float().mean(dim=node.attrs["axis"])
@@ -811,7 +833,7 @@ nn = types.SimpleNamespace(softmax_cross_entropy_with_logits=_softmax_xent,
                            softmax_cross_entropy_with_logits_v2=_softmax_xent,
                            sparse_softmax_cross_entropy_with_logits=_sparse_softmax_xent,
                            sigmoid=sigmoid, tanh=tanh, relu=_relu, softmax=_softmax, bias_add=_bias_add,
-                           dropout=_nn_dropout)
+                           dropout=_nn_dropout, conv2d=_nn_conv2d, max_pool=_nn_max_pool)
 layers = types.SimpleNamespace(dense=_layers_dense)
 
 summary = types.SimpleNamespace(scalar=_summary.scalar, merge_all=_summary.merge_all, merge=_summary.merge,

@@ -90,6 +90,23 @@ class GraphModel(Sequential):
                     else (ins[1] if len(ins) > 1 else None)
             elif n.op in ("relu", "sigmoid", "tanh", "softmax", "nn_dropout", "round", "square", "cast"):
                 shapes[id(n)] = ins[0]
+            elif n.op in ("conv2d", "max_pool") and ins[0] is not None and len(ins[0]) == 3:
+                from ..ops.functional import conv_geometry
+                h, w, c = ins[0]
+                kh, kw = (n.inputs[1].shape[:2] if n.op == "conv2d" else n.attrs["ksize"])
+                oh, ow = conv_geometry(h, w, int(kh), int(kw), n.attrs["strides"], n.attrs["padding"])[:2]
+                shapes[id(n)] = (oh, ow, int(n.inputs[1].shape[3]) if n.op == "conv2d" else c)
+            elif n.op == "reshape":
+                tail = [int(s) for s in n.attrs["shape"][1:]]
+                if -1 in tail and ins[0] is not None:
+                    known = 1
+                    for s in tail:
+                        known *= s if s != -1 else 1
+                    total = 1
+                    for s in ins[0]:
+                        total *= s
+                    tail[tail.index(-1)] = total // max(known, 1)
+                shapes[id(n)] = tuple(tail) if -1 not in tail else None
             else:
                 shapes[id(n)] = None
         return shapes
@@ -208,6 +225,12 @@ class GraphModel(Sequential):
                 out = A.activation(ins[0], "sigmoid")
             elif op == "tanh":
                 out = A.activation(ins[0], "tanh")
+            elif op == "conv2d":
+                out = A.conv2d(ins[0], ins[1], None, node.attrs["strides"], node.attrs["padding"], None)
+            elif op == "max_pool":
+                out = A.max_pool2d(ins[0], node.attrs["ksize"], node.attrs["strides"], node.attrs["padding"])
+            elif op == "reshape":
+                out = ins[0].reshape(node.attrs["shape"])
             elif op == "softmax":
                 out = torch.softmax(ins[0], dim=-1)
             elif op == "nn_dropout":

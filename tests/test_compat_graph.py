@@ -326,3 +326,76 @@ def test_sync_replicas_optimizer_refuses_a_partial_aggregate():
     finally:
         dist.destroy_process_group()
         tf.reset_default_graph()
+
+
+def test_tf1_deep_mnist_tutorial_graph_with_raw_ops():
+    _deep_mnist_with_raw_ops()
+
+
+@pytest.mark.gpu
+def test_tf1_deep_mnist_tutorial_graph_with_raw_ops_gpu(gpu_device):
+    assert _deep_mnist_with_raw_ops().type == "cuda"
+
+
+def _deep_mnist_with_raw_ops():
+    """The classic TF1 convolutional MNIST graph written with raw ops - ``tf.reshape``, ``tf.nn.conv2d`` +
+    bias + ``tf.nn.relu``, ``tf.nn.max_pool``, hand-written ``tf.Variable``s, ``tf.matmul`` - trains through the graph
+    model (the convolutions and poolings run on the same kernels as the Keras layers) and matches a PyTorch replica
+    of the same graph step for step."""
+    import torch
+    from distributed_tensorflow_amd.data import mnist_like
+    tf.reset_default_graph()
+    x = tf.placeholder(tf.float32, [None, 784])
+    y_ = tf.placeholder(tf.float32, [None, 10])
+    x_image = tf.reshape(x, [-1, 28, 28, 1])
+    W1 = tf.Variable(tf.truncated_normal([5, 5, 1, 8], stddev=0.1), name="W_conv1")
+    b1 = tf.Variable(tf.constant(0.1, shape=[8]), name="b_conv1")
+    h1 = tf.nn.relu(tf.nn.conv2d(x_image, W1, strides=[1, 1, 1, 1], padding="SAME") + b1)
+    p1 = tf.nn.max_pool(h1, ksize=[1, 2, 2, 1], strides=[1, 2, 2, 1], padding="SAME")
+    W2 = tf.Variable(tf.truncated_normal([3, 3, 8, 16], stddev=0.1), name="W_conv2")
+    b2 = tf.Variable(tf.constant(0.1, shape=[16]), name="b_conv2")
+    h2 = tf.nn.relu(tf.nn.conv2d(p1, W2, strides=[1, 1, 1, 1], padding="SAME") + b2)
+    p2 = tf.nn.max_pool(h2, ksize=[1, 2, 2, 1], strides=[1, 2, 2, 1], padding="SAME")
+    flat = tf.reshape(p2, [-1, 7 * 7 * 16])
+    Wf = tf.Variable(tf.truncated_normal([7 * 7 * 16, 32], stddev=0.1), name="W_fc1")
+    bf = tf.Variable(tf.constant(0.1, shape=[32]), name="b_fc1")
+    hf = tf.nn.relu(tf.matmul(flat, Wf) + bf)
+    Wo = tf.Variable(tf.truncated_normal([32, 10], stddev=0.1), name="W_fc2")
+    bo = tf.Variable(tf.constant(0.1, shape=[10]), name="b_fc2")
+    logits = tf.matmul(hf, Wo) + bo
+    loss = tf.reduce_mean(tf.nn.softmax_cross_entropy_with_logits(labels=y_, logits=logits))
+    train = tf.train.GradientDescentOptimizer(0.1).minimize(loss)
+    acc = tf.reduce_mean(tf.cast(tf.equal(tf.argmax(logits, 1), tf.argmax(y_, 1)), tf.float32))
+
+    xs, ys = mnist_like(96, seed=3)
+    yo = torch.nn.functional.one_hot(ys, 10).float()
+    got = []
+    with tf.Session() as sess:
+        sess.run(tf.global_variables_initializer())
+        eng = tf.get_default_graph().engine()
+        assert eng.dag
+        w = {v.name: v.tensor.detach().cpu().clone().double().requires_grad_(True) for v in eng.model.store.trainable}
+        assert set(w) == {"W_conv1", "b_conv1", "W_conv2", "b_conv2", "W_fc1", "b_fc1", "W_fc2", "b_fc2"}
+        for i in range(6):
+            l, _ = sess.run([loss, train], {x: xs.numpy(), y_: yo.numpy()})
+            got.append(l)
+        a = sess.run(acc, {x: xs.numpy(), y_: yo.numpy()})
+    # the same graph in PyTorch (fp64), plain gradient descent
+    want = []
+    fn = torch.nn.functional
+    for i in range(6):
+        h = xs.double().reshape(-1, 1, 28, 28)
+        h = fn.max_pool2d(torch.relu(fn.conv2d(h, w["W_conv1"].permute(3, 2, 0, 1), w["b_conv1"], padding=2)), 2)
+        h = fn.max_pool2d(torch.relu(fn.conv2d(h, w["W_conv2"].permute(3, 2, 0, 1), w["b_conv2"], padding=1)), 2)
+        h = h.permute(0, 2, 3, 1).reshape(-1, 7 * 7 * 16)
+        h = torch.relu(h @ w["W_fc1"] + w["b_fc1"])
+        lo = fn.cross_entropy(h @ w["W_fc2"] + w["b_fc2"], ys)
+        want.append(lo.item())
+        grads = torch.autograd.grad(lo, list(w.values()))
+        with torch.no_grad():
+            for t, g in zip(w.values(), grads):
+                t -= 0.1 * g
+    assert max(abs(p - q) for p, q in zip(got, want)) < 2e-4, (got, want)
+    assert got[-1] < got[0] and 0.0 <= a <= 1.0
+    tf.reset_default_graph()
+    return eng.model.device
