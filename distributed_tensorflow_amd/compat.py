@@ -308,9 +308,13 @@ def reshape(tensor, shape, name=None):
     """``tf.reshape`` with a static shape (one -1 allowed, typically the batch dimension)."""
     return Tensor("reshape", [tensor], {"shape": tuple(int(s) for s in shape)}, name=name or "Reshape")
 def _nn_dropout(x, keep_prob, noise_shape=None, seed=None, name=None):
+    """``tf.nn.dropout``.  A Python ``keep_prob`` follows ``K.learning_phase()`` like the Keras layer (the reference
+    script's way of switching); a fed ``keep_prob`` placeholder (the TF1 tutorials' way: 0.5 while training, 1.0 for
+    evaluation) is applied as fed, whatever the learning phase - such a graph runs as a graph model."""
+    if isinstance(keep_prob, Tensor):
+        return Tensor("nn_dropout", [x, keep_prob], {"keep_prob": None}, name=name or "dropout")
     if not isinstance(keep_prob, (int, float)):
-        raise NotImplementedError("tf.nn.dropout: keep_prob must be a Python number here (training / evaluation is "
-                                  "switched with K.learning_phase(), as in the reference script)")
+        raise NotImplementedError("tf.nn.dropout: keep_prob must be a Python number or a fed placeholder")
     return Tensor("nn_dropout", [x], {"keep_prob": float(keep_prob)}, name=name or "dropout")
 
 
@@ -508,6 +512,8 @@ class GraphEngine(ModelEngine):
                 node = node.inputs[0]
                 continue
             if node.op == "nn_dropout":
+                if node.attrs["keep_prob"] is None:
+                    raise NotImplementedError("a fed keep_prob makes the graph a graph model")
                 layer = _layers.Dropout(1.0 - node.attrs["keep_prob"])
                 chain.append(layer)
                 self.lowered[node] = (layer, node.inputs[0])

@@ -235,7 +235,11 @@ class GraphModel(Sequential):
                 out = torch.softmax(ins[0], dim=-1)
             elif op == "nn_dropout":
                 seed = node.attrs.setdefault("_seed", (hash(node.name) & 0x7FFFFFF) + 1)
-                out = A.dropout(ins[0], 1.0 - node.attrs["keep_prob"], seed, self.store.global_step, training)
+                if node.attrs["keep_prob"] is None:      # a fed keep probability: applied as fed (one host read per run)
+                    keep = float(ins[1])
+                    out = A.dropout(ins[0], 1.0 - keep, seed, self.store.global_step, keep < 1.0)
+                else:
+                    out = A.dropout(ins[0], 1.0 - node.attrs["keep_prob"], seed, self.store.global_step, training)
             elif op == "square":
                 out = ins[0] * ins[0]
             elif op == "round":

@@ -360,6 +360,8 @@ def _deep_mnist_with_raw_ops():
     Wf = tf.Variable(tf.truncated_normal([7 * 7 * 16, 32], stddev=0.1), name="W_fc1")
     bf = tf.Variable(tf.constant(0.1, shape=[32]), name="b_fc1")
     hf = tf.nn.relu(tf.matmul(flat, Wf) + bf)
+    keep_prob = tf.placeholder(tf.float32)                    # fed: 1.0 here, so that the PyTorch replica needs no mask
+    hf = tf.nn.dropout(hf, keep_prob)
     Wo = tf.Variable(tf.truncated_normal([32, 10], stddev=0.1), name="W_fc2")
     bo = tf.Variable(tf.constant(0.1, shape=[10]), name="b_fc2")
     logits = tf.matmul(hf, Wo) + bo
@@ -377,9 +379,12 @@ def _deep_mnist_with_raw_ops():
         w = {v.name: v.tensor.detach().cpu().clone().double().requires_grad_(True) for v in eng.model.store.trainable}
         assert set(w) == {"W_conv1", "b_conv1", "W_conv2", "b_conv2", "W_fc1", "b_fc1", "W_fc2", "b_fc2"}
         for i in range(6):
-            l, _ = sess.run([loss, train], {x: xs.numpy(), y_: yo.numpy()})
+            l, _ = sess.run([loss, train], {x: xs.numpy(), y_: yo.numpy(), keep_prob: 1.0})
             got.append(l)
-        a = sess.run(acc, {x: xs.numpy(), y_: yo.numpy()})
+        a = sess.run(acc, {x: xs.numpy(), y_: yo.numpy(), keep_prob: 1.0})
+        dropped = sess.run(loss, {x: xs.numpy(), y_: yo.numpy(), keep_prob: 0.5})
+        kept = sess.run(loss, {x: xs.numpy(), y_: yo.numpy(), keep_prob: 1.0})
+        assert dropped != kept                                # the fed value is what is applied
     # the same graph in PyTorch (fp64), plain gradient descent
     want = []
     fn = torch.nn.functional
