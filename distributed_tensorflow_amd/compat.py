@@ -764,6 +764,66 @@ def _monitored_training_session(*args, **kwargs):
     return _SessionWrapper(_session.MonitoredTrainingSession(*args, **kwargs))
 
 
+class Supervisor:
+    """``tf.train.Supervisor``, the session manager distributed TF1 scripts used before ``MonitoredTrainingSession``
+    (the other way of writing what /root/reference/example.py:189-192 does)::
+
+        sv = tf.train.Supervisor(is_chief=(task_index == 0), logdir=log_dir, global_step=global_step)
+        sess = sv.prepare_or_wait_for_session(server.target)        # chief initialises / restores, the others wait
+        while not sv.should_stop() and step < last: _, step = sess.run([train_op, global_step], feed)
+        sv.stop()
+
+    It is a thin front of the same monitored session: ``logdir`` is its checkpoint directory (the chief saves every
+    ``save_model_secs`` and at ``stop``), ``managed_session`` is the ``with`` form.  ``init_op`` / ``saver`` /
+    ``summary_op`` arguments are accepted for compatibility: initialisation, the saver and the summaries are the
+    session's own."""
+
+    def __init__(self, graph=None, is_chief: bool = True, logdir: Optional[str] = None, init_op=None, saver=None,
+                 global_step=None, save_model_secs: float = 600, save_summaries_secs: float = 120,
+                 recovery_wait_secs: float = 30, summary_op=None, **_):
+        self.is_chief, self.logdir = bool(is_chief), logdir
+        self.save_model_secs = save_model_secs
+        self._graph = graph
+        self._sess = None
+
+    def prepare_or_wait_for_session(self, master: str = "", config=None, **_):
+        if self._sess is None:
+            g = self._graph or get_default_graph()
+            # no summary hook: TF's Supervisor ran summaries from a thread of its own, which cannot feed placeholders;
+            # scripts of this style write theirs through an explicit FileWriter
+            inner = _session.MonitoredTrainingSession(master=master, is_chief=self.is_chief, checkpoint_dir=self.logdir,
+                                                      save_checkpoint_secs=self.save_model_secs or None,
+                                                      save_summaries_steps=None, engine=g.engine())
+            self._sess = _SessionWrapper(inner)
+            self._sess.__enter__()
+        return self._sess
+
+    def managed_session(self, master: str = "", config=None, **_):
+        sv = self
+
+        class _Managed:
+            def __enter__(self_inner):
+                return sv.prepare_or_wait_for_session(master)
+
+            def __exit__(self_inner, *exc):
+                sv.stop()
+                return False
+        return _Managed()
+
+    def should_stop(self) -> bool:
+        return self._sess is not None and self._sess.should_stop()
+
+    def request_stop(self, ex=None):
+        if self._sess is not None:
+            self._sess.request_stop()
+
+    def stop(self, *_, **__):
+        """Ends the session: the chief's final checkpoint is written here."""
+        if self._sess is not None:
+            sess, self._sess = self._sess, None
+            sess.__exit__(None, None, None)
+
+
 def Session(target: str = "", graph: Optional[Graph] = None, config=None):
     """Plain ``tf.Session``: a monitored session without hooks or checkpoints."""
     g = graph or get_default_graph()
@@ -853,7 +913,7 @@ train = types.SimpleNamespace(
     StepCounterHook=_session.StepCounterHook, SummarySaverHook=_session.SummarySaverHook,
     CheckpointSaverHook=_session.CheckpointSaverHook, LoggingTensorHook=_session.LoggingTensorHook,
     SessionRunHook=_session.SessionRunHook, SessionRunArgs=_session.SessionRunArgs, Scaffold=_session.Scaffold,
-    MonitoredTrainingSession=_monitored_training_session, Saver=_saver.Saver,
+    MonitoredTrainingSession=_monitored_training_session, Supervisor=Supervisor, Saver=_saver.Saver,
     latest_checkpoint=_saver.latest_checkpoint, load_checkpoint=_saver.load_checkpoint,
     list_variables=_saver.list_variables)
 

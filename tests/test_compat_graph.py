@@ -404,3 +404,33 @@ def _deep_mnist_with_raw_ops():
     assert got[-1] < got[0] and 0.0 <= a <= 1.0
     tf.reset_default_graph()
     return eng.model.device
+
+
+def test_supervisor_style_script(tmp_path):
+    """The older way of writing the reference's session: ``tf.train.Supervisor`` + ``prepare_or_wait_for_session`` +
+    ``sv.stop()``, with checkpoints in ``logdir`` and a resume from them."""
+    data = get_data(500, seed=1)
+
+    def run(last):
+        tf.reset_default_graph()
+        g = build_graph()
+        sv = tf.train.Supervisor(is_chief=True, logdir=str(tmp_path), global_step=g["global_step"], save_model_secs=600)
+        sess = sv.prepare_or_wait_for_session("")
+        start = step = sess.run(g["global_step"])
+        xt, yt = data[0], data[1]
+        while not sv.should_stop() and step < last:
+            i = step % 10
+            _, step = sess.run([g["train"], g["global_step"]],
+                               feed_dict={g["input"]: xt[i * 50:(i + 1) * 50], g["labels"]: yt[i * 50:(i + 1) * 50],
+                                          K.learning_phase(): 1})
+        sv.stop()
+        return start, step
+
+    assert run(30) == (0, 30)
+    assert latest_checkpoint(str(tmp_path)).endswith("model.ckpt-30")
+    assert run(45) == (30, 45)                    # a second run continues from the checkpoint, as with TF
+    tf.reset_default_graph()
+    g = build_graph()
+    with tf.train.Supervisor(is_chief=True, logdir=None).managed_session("") as sess:      # the `with` form, no logdir
+        assert sess.run(g["global_step"]) == 0
+    tf.reset_default_graph()

@@ -94,3 +94,41 @@ def test_one_ps_two_workers(tmp_path, mode):
         assert step <= int(r.get_tensor("global_step").item()) <= step + 2
         assert r.get_tensor("dense_1/kernel").abs().sum() > 0
     assert glob.glob(os.path.join(str(tmp_path), "events.out.tfevents.*"))
+
+
+def test_supervisor_style_replica_script(tmp_path):
+    """``examples/supervisor_replica.py``: 1 ps + 2 workers of a script written with ``tf.train.Supervisor`` and raw
+    ``tf.Variable`` / ``tf.matmul`` ops; shared global step, chief's checkpoint in ``--train_dir`` with the script's own
+    variable names."""
+    script = os.path.join(ROOT, "examples", "supervisor_replica.py")
+    ps_port, w0, w1, rdv = _ports(4)
+    args = [sys.executable, script, "--ps_hosts", "127.0.0.1:%d" % ps_port,
+            "--worker_hosts", "127.0.0.1:%d,127.0.0.1:%d" % (w0, w1), "--train_dir", str(tmp_path), "--train_steps", "80"]
+    procs, logs = {}, {}
+    try:
+        for job, idx in (("ps", 0), ("worker", 0), ("worker", 1)):
+            logs[(job, idx)] = open(str(tmp_path / ("%s%d.log" % (job, idx))), "w+")
+            procs[(job, idx)] = subprocess.Popen(args + ["--job_name", job, "--task_index", str(idx)],
+                                                 env=_env({"DTF_RENDEZVOUS_PORT": str(rdv)}), stdout=logs[(job, idx)],
+                                                 stderr=subprocess.STDOUT)
+        texts = {}
+        for key in (("worker", 0), ("worker", 1), ("ps", 0)):
+            try:
+                rc = procs[key].wait(timeout=240)
+            except subprocess.TimeoutExpired:
+                rc = None
+            logs[key].seek(0)
+            texts[key] = logs[key].read()
+            assert rc == 0, "%s%d rc=%s\n%s" % (key[0], key[1], rc, texts[key][-3000:])
+    finally:
+        for p in procs.values():
+            if p.poll() is None:
+                p.kill()
+        for f in logs.values():
+            f.close()
+    for idx in (0, 1):
+        assert "Worker %d: session ready" % idx in texts[("worker", idx)] and "done after" in texts[("worker", idx)]
+    ck = latest_checkpoint(str(tmp_path))
+    assert ck is not None and 80 <= int(ck.rsplit("-", 1)[1]) <= 86
+    names = dict(list_variables(ck))
+    assert names["hid_w"] == (784, 100) and names["sm_b"] == (10,) and "hid_w/Adam_1" in names
