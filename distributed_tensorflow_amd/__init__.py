@@ -6,5 +6,6 @@ TensorFlow-compatible (TensorBundle) checkpoints."""
 __version__ = "0.1.0"
 
 from . import callbacks, data, layers, losses, models, optimizers  # noqa: F401
-from .layers import Activation, BatchNormalization, Conv2D, Dense, Dropout, Flatten, MaxPooling2D  # noqa: F401
+from .layers import (Activation, AveragePooling2D, BatchNormalization, Conv2D, Dense, Dropout, Flatten,  # noqa: F401
+                     GlobalAveragePooling2D, MaxPooling2D)
 from .models import Sequential  # noqa: F401

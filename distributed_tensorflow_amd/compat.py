@@ -959,6 +959,14 @@ class _BatchNormalization(_SymbolicLayerMixin, _layers.BatchNormalization):
     pass
 
 
+class _AveragePooling2D(_SymbolicLayerMixin, _layers.AveragePooling2D):
+    pass
+
+
+class _GlobalAveragePooling2D(_SymbolicLayerMixin, _layers.GlobalAveragePooling2D):
+    pass
+
+
 class _KerasBackend:
     _session = None
 
@@ -992,7 +1000,8 @@ def _keras_bce(y_true, y_pred):
 
 keras = types.SimpleNamespace(
     layers=types.SimpleNamespace(Dense=_Dense, Dropout=_Dropout, Activation=_Activation, Flatten=_Flatten,
-                                 Conv2D=_Conv2D, MaxPooling2D=_MaxPooling2D, BatchNormalization=_BatchNormalization),
+                                 Conv2D=_Conv2D, MaxPooling2D=_MaxPooling2D, BatchNormalization=_BatchNormalization,
+                                 AveragePooling2D=_AveragePooling2D, GlobalAveragePooling2D=_GlobalAveragePooling2D),
     models=types.SimpleNamespace(Sequential=_Sequential),
     backend=_KerasBackend,
     losses=types.SimpleNamespace(mean_squared_error=_keras_mse, binary_crossentropy=_keras_bce),

@@ -743,9 +743,78 @@ class MaxPooling2D(Layer):
                 "padding": self.padding}
 
 
+class AveragePooling2D(Layer):
+    """NHWC average pooling (Keras ``AveragePooling2D``): any window and strides, ``valid`` or ``same`` padding; windows
+    over the border average over their in-image positions."""
+
+    prefix = "average_pooling2d"
+
+    def __init__(self, pool_size=(2, 2), strides=None, padding: str = "valid", name=None):
+        super().__init__(name=name)
+        self.pool_size = _pair(pool_size)
+        self.strides = _pair(strides) if strides is not None else self.pool_size
+        self.padding = str(padding).lower()
+        if self.padding not in ("valid", "same"):
+            raise ValueError("AveragePooling2D: padding must be 'valid' or 'same'")
+        self._buf = _Buffers()
+        self._in_shape = None
+
+    def get_config(self):
+        return {"class": type(self).__name__, "name": self.name, "pool_size": list(self.pool_size),
+                "strides": list(self.strides), "padding": self.padding}
+
+    def compute_output_shape(self, input_shape):
+        if len(input_shape) != 3:
+            raise ValueError("%s expects per-example shape (H, W, C), got %s" % (type(self).__name__, input_shape))
+        H, W, C = input_shape
+        OH, OW = F.pool_geometry(H, W, *self.pool_size, self.strides, self.padding)[:2]
+        if OH <= 0 or OW <= 0:
+            raise ValueError("pool %s does not fit input %s" % (self.pool_size, input_shape))
+        return (OH, OW, C)
+
+    def forward(self, x, training):
+        x = x.contiguous()
+        self._in_shape = tuple(x.shape)
+        y = self._buf.get("y", (x.shape[0],) + tuple(self.output_shape), x.device)
+        return F.avgpool_forward(x, self.pool_size, self.strides, self.padding, out=y)
+
+    def backward(self, dy):
+        dx = self._buf.get("dx", self._in_shape, dy.device)
+        return F.avgpool_backward(dy.contiguous(), self._in_shape, self.pool_size, self.strides, self.padding, out=dx)
+
+
+class GlobalAveragePooling2D(Layer):
+    """Mean over the spatial axes: ``[B, H, W, C] -> [B, C]`` (one averaging window as large as the feature map)."""
+
+    prefix = "global_average_pooling2d"
+
+    def __init__(self, name=None):
+        super().__init__(name=name)
+        self._buf = _Buffers()
+        self._in_shape = None
+
+    def compute_output_shape(self, input_shape):
+        if len(input_shape) != 3:
+            raise ValueError("GlobalAveragePooling2D expects per-example shape (H, W, C), got %s" % (input_shape,))
+        return (int(input_shape[2]),)
+
+    def forward(self, x, training):
+        x = x.contiguous()
+        B, H, W, C = x.shape
+        self._in_shape = (B, H, W, C)
+        y = self._buf.get("y", (B, 1, 1, C), x.device)
+        return F.avgpool_forward(x, (H, W), (H, W), "valid", out=y).view(B, C)
+
+    def backward(self, dy):
+        B, H, W, C = self._in_shape
+        dx = self._buf.get("dx", self._in_shape, dy.device)
+        return F.avgpool_backward(dy.contiguous().view(B, 1, 1, C), self._in_shape, (H, W), (H, W), "valid", out=dx)
+
+
 def layer_from_config(cfg: dict) -> Layer:
     """Rebuild a layer from its ``get_config()`` dictionary (``class`` names the layer type)."""
-    classes = {c.__name__: c for c in (Dense, Dropout, Activation, Flatten, Conv2D, MaxPooling2D, BatchNormalization)}
+    classes = {c.__name__: c for c in (Dense, Dropout, Activation, Flatten, Conv2D, MaxPooling2D, BatchNormalization,
+                                       AveragePooling2D, GlobalAveragePooling2D)}
     kw = {k: v for k, v in cfg.items() if k != "class"}
     try:
         cls = classes[cfg["class"]]

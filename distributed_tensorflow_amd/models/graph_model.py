@@ -172,6 +172,10 @@ class GraphModel(Sequential):
                             {0: None, 1: "relu", 2: "sigmoid", 3: "tanh"}[layer.act])
         if isinstance(layer, L.MaxPooling2D):
             return A.max_pool2d(x, layer.pool_size, layer.strides, layer.padding)
+        if isinstance(layer, L.AveragePooling2D):
+            return A.avg_pool2d(x, layer.pool_size, layer.strides, layer.padding)
+        if isinstance(layer, L.GlobalAveragePooling2D):
+            return A.avg_pool2d(x, tuple(x.shape[1:3]), tuple(x.shape[1:3]), "valid").reshape(x.shape[0], x.shape[3])
         if isinstance(layer, L.BatchNormalization):
             return A.batch_norm(x, self._leaf(layer.gamma) if layer.gamma is not None else None,
                                 self._leaf(layer.beta) if layer.beta is not None else None, layer.moving_mean.tensor,

@@ -86,6 +86,8 @@ def kernels():
         "dtf_softmax_rows": [c_p, c_p, c_i, c_i, c_p],
         "dtf_im2col": [c_p, c_p] + [c_i] * 12 + [c_p],
         "dtf_col2im": [c_p, c_p, c_p] + [c_i] * 12 + [c_p],
+        "dtf_avgpool_fwd": [c_p, c_p] + [c_i] * 12 + [c_p],
+        "dtf_avgpool_bwd": [c_p, c_p] + [c_i] * 12 + [c_p],
         "dtf_maxpool_fwd": [c_p, c_p, c_p] + [c_i] * 6 + [c_p],
         "dtf_maxpool_strided_fwd": [c_p, c_p, c_p] + [c_i] * 12 + [c_p],
         "dtf_maxpool_strided_bwd": [c_p, c_p, c_p, c_p] + [c_i] * 12 + [c_p],

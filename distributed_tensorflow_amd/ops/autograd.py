@@ -249,6 +249,25 @@ def max_pool2d(x, pool=(2, 2), strides=None, padding="valid"):
     return _MaxPoolFn.apply(x, pool, tuple(strides) if strides is not None else pool, str(padding).lower())
 
 
+class _AvgPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, pool, strides, padding):
+        x = _c(x)
+        ctx.cfg = (tuple(x.shape), pool, strides, padding)
+        return F.avgpool_forward(x, pool, strides, padding)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xshape, pool, strides, padding = ctx.cfg
+        return F.avgpool_backward(_c(dy), xshape, pool, strides, padding), None, None, None
+
+
+def avg_pool2d(x, pool=(2, 2), strides=None, padding="valid"):
+    """Average pooling of an NHWC tensor (windows over the border average over their in-image positions)."""
+    pool = tuple(pool)
+    return _AvgPoolFn.apply(x, pool, tuple(strides) if strides is not None else pool, str(padding).lower())
+
+
 class _BatchNormFn(torch.autograd.Function):
     """Batch normalisation over the last axis (Keras semantics); ``moving_mean`` / ``moving_var`` are updated in place
     while training.  Gradients flow to ``x``, ``gamma`` and ``beta``."""

@@ -850,6 +850,63 @@ def pool_geometry(H, W, PH, PW, strides, padding="valid"):
     return OH, OW, pt, pl
 
 
+def _avg_counts(H, W, PH, PW, strides, padding, device):
+    """Number of in-image positions of every pooling window, ``[OH, OW]``."""
+    OH, OW, pt, pl = pool_geometry(H, W, PH, PW, strides, padding)
+    oh = torch.arange(OH, device=device) * strides[0] - pt
+    ow = torch.arange(OW, device=device) * strides[1] - pl
+    ch = (oh + PH).clamp(max=H) - oh.clamp(min=0)
+    cw = (ow + PW).clamp(max=W) - ow.clamp(min=0)
+    return (ch[:, None] * cw[None, :]).to(torch.float32)
+
+
+def avgpool_forward(x, pool=(2, 2), strides=None, padding="valid", out=None):
+    """Average pooling of an NHWC tensor; a window over the border averages over its in-image positions (TensorFlow)."""
+    B, H, W, C = x.shape
+    PH, PW = pool
+    strides = tuple(strides) if strides is not None else (PH, PW)
+    OH, OW, pt, pl = pool_geometry(H, W, PH, PW, strides, padding)
+    if out is None:
+        out = torch.empty((B, OH, OW, C), dtype=torch.float32, device=x.device)
+    if x.is_cuda:
+        nv.require_f32_contig(x, out)
+        rc = nv.kernels().dtf_avgpool_fwd(nv.ptr(x), nv.ptr(out), B, H, W, C, PH, PW, strides[0], strides[1], OH, OW, pt, pl,
+                                          nv.stream_ptr())
+        nv.check(rc, "dtf_avgpool_fwd")
+        return out
+    pb = max((OH - 1) * strides[0] + PH - H - pt, 0)
+    pr = max((OW - 1) * strides[1] + PW - W - pl, 0)
+    xp = torch.nn.functional.pad(x.permute(0, 3, 1, 2), (pl, pr, pt, pb))
+    sums = torch.nn.functional.avg_pool2d(xp, (PH, PW), strides, divisor_override=1)
+    out.copy_((sums / _avg_counts(H, W, PH, PW, strides, padding, x.device)).permute(0, 2, 3, 1))
+    return out
+
+
+def avgpool_backward(dy, x_shape, pool=(2, 2), strides=None, padding="valid", out=None):
+    """Gradient of ``avgpool_forward``: every input position collects ``dy / count`` of the windows that cover it."""
+    B, H, W, C = x_shape
+    PH, PW = pool
+    strides = tuple(strides) if strides is not None else (PH, PW)
+    OH, OW, pt, pl = pool_geometry(H, W, PH, PW, strides, padding)
+    if out is None:
+        out = torch.empty(tuple(x_shape), dtype=torch.float32, device=dy.device)
+    if dy.is_cuda:
+        nv.require_f32_contig(dy, out)
+        rc = nv.kernels().dtf_avgpool_bwd(nv.ptr(dy), nv.ptr(out), B, H, W, C, PH, PW, strides[0], strides[1], OH, OW, pt, pl,
+                                          nv.stream_ptr())
+        nv.check(rc, "dtf_avgpool_bwd")
+        return out
+    # reference path: scatter dy / count back through the windows
+    g = (dy / _avg_counts(H, W, PH, PW, strides, padding, dy.device)[None, :, :, None]).permute(0, 3, 1, 2)
+    pb = max((OH - 1) * strides[0] + PH - H - pt, 0)
+    pr = max((OW - 1) * strides[1] + PW - W - pl, 0)
+    Hp, Wp = H + pt + pb, W + pl + pr
+    cols = g.reshape(B, C, 1, OH * OW).expand(B, C, PH * PW, OH * OW).reshape(B, C * PH * PW, OH * OW)
+    full = torch.nn.functional.fold(cols, (Hp, Wp), (PH, PW), stride=strides)
+    out.copy_(full[:, :, pt:pt + H, pl:pl + W].permute(0, 2, 3, 1))
+    return out
+
+
 def maxpool_strided_forward(x, pool=(2, 2), strides=(2, 2), padding="valid", out=None, arg=None):
     """Max pooling of an NHWC tensor with any window, strides and VALID / SAME padding; returns ``(y, arg)`` with
     ``arg`` the window position ``i * PW + j`` of each maximum."""
