@@ -489,11 +489,15 @@ class Sequential:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         saved_stats = self.stats.clone()
+        saved_other = {v.name: v.tensor.clone() for v in self.store.variables.values()
+                       if not v.trainable and v.tensor is not None}       # moving averages: the forward pass writes them
         with torch.cuda.stream(side):
             self.compute_gradients(x_buf, y_buf)       # warm-up: every lazily allocated buffer exists afterwards
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.stats.copy_(saved_stats)
+        for name, t in saved_other.items():
+            self.store.variables[name].tensor.copy_(t)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, capture_error_mode="thread_local"):   # other threads (RCCL watchdog) keep working
             self.compute_gradients(x_buf, y_buf)
@@ -559,8 +563,11 @@ class Sequential:
 
     def _snapshot(self):
         st = self.store
+        # everything a training step writes: variables, slots, counters, statistics - and the variables that are not
+        # trained but updated by the forward pass (moving averages of batch normalisation)
+        other = {v.name: v.tensor.clone() for v in st.variables.values() if not v.trainable and v.tensor is not None}
         return (st.flat.clone(), {k: v.clone() for k, v in st.slots.items()}, st.global_step.clone(),
-                st.beta_powers.clone(), self.stats.clone())
+                st.beta_powers.clone(), self.stats.clone(), other)
 
     def _restore(self, saved):
         st = self.store
@@ -570,6 +577,8 @@ class Sequential:
         st.global_step.copy_(saved[2])
         st.beta_powers.copy_(saved[3])
         self.stats.copy_(saved[4])
+        for name, t in saved[5].items():
+            st.variables[name].tensor.copy_(t)
 
     # ------------------------------------------------------------------ fit
     def fit(self, x, y, epochs: int = 1, batch_size: int = 32, validation_data=None, callbacks=None,

@@ -239,3 +239,21 @@ def test_graph_model_with_a_skip_connection_uses_it():
         last = sess.run(loss, {x: bx, y: by, K.learning_phase(): 0})       # inference mode: the moving statistics
         mv = eng.model.store.variables["batch_normalization_1/moving_variance"].tensor
     assert last < first and not torch.allclose(mv.cpu(), torch.ones(16))
+
+
+@pytest.mark.gpu
+def test_graph_replay_equals_eager_with_batchnorm(gpu_device):
+    """``fit(steps_per_graph=N)``: the batch-normalisation kernels (statistics, moving averages, gradients) replay from
+    a captured hipGraph exactly as they run eagerly."""
+    from distributed_tensorflow_amd.data import mnist_like
+    x, y = mnist_like(1024, seed=2, device=gpu_device)
+    finals = []
+    for spg in (0, 4):
+        m = Sequential([Dense(32, input_dim=784), BatchNormalization(momentum=0.9), Dense(32, activation="relu"),
+                        Dense(10, activation="softmax")])
+        m.compile(loss="sparse_categorical_crossentropy", optimizer="adam", metrics=["accuracy"], device=gpu_device, seed=5)
+        m.fit(x, y, epochs=2, batch_size=128, shuffle=False, verbose=0, steps_per_graph=spg, fused=False)
+        finals.append((m.store.flat.clone(), m.store.variables["batch_normalization_1/moving_variance"].tensor.clone()))
+    torch.testing.assert_close(finals[0][0], finals[1][0], rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(finals[0][1], finals[1][1], rtol=1e-6, atol=1e-7)
+    assert not torch.allclose(finals[0][1].cpu(), torch.ones(32))
