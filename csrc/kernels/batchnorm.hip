@@ -105,17 +105,20 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
     }
 }
 
-// Sum of the G partial pairs of one channel, in fp64 and in a fixed order.  A block of 256 threads takes 32 channels:
-// eight lanes per channel add every eighth partial (coalesced 128-byte reads across the channels), then lane 0 adds
-// the eight.  Returns the channel for the thread that holds the result, -1 for all others.
+// Sum of the G partial pairs of one channel, in fp64 and in a fixed order.  A block of 256 threads takes 8 channels:
+// thirty-two lanes per channel add every thirty-second partial (the chain of dependent additions is what this small
+// kernel's time consists of: G / 32 links), then lane 0 adds the thirty-two.  Returns the channel for the thread
+// that holds the result, -1 for all others.
+constexpr int BN_FIN_CH = 8, BN_FIN_LANES = 32;
+
 __device__ __forceinline__ int bn_sum_partials(const float* __restrict__ slab, int G, int C, double& s0, double& s1) {
-    __shared__ double part[2][8][32];
-    const int cl = threadIdx.x & 31, gl = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
+    __shared__ double part[2][BN_FIN_LANES][BN_FIN_CH];
+    const int cl = threadIdx.x % BN_FIN_CH, gl = threadIdx.x / BN_FIN_CH;
+    const int c = blockIdx.x * BN_FIN_CH + cl;
     double a0 = 0.0, a1 = 0.0;
     if (c < C) {
 #pragma unroll 4
-        for (int g = gl; g < G; g += 8) {
+        for (int g = gl; g < G; g += BN_FIN_LANES) {
             a0 += (double)slab[(long long)g * 2 * C + c];
             a1 += (double)slab[(long long)g * 2 * C + C + c];
         }
@@ -126,7 +129,7 @@ __device__ __forceinline__ int bn_sum_partials(const float* __restrict__ slab, i
     if (gl != 0 || c >= C) return -1;
     s0 = s1 = 0.0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < BN_FIN_LANES; ++k) {
         s0 += part[0][k][cl];
         s1 += part[1][k][cl];
     }
@@ -264,7 +267,7 @@ DTF_API int dtf_batchnorm_fwd(const float* X, float* Y, long long R, int C, cons
             hipLaunchKernelGGL((bn_partial_kernel<1, false>), dim3(G), dim3(256), 0, stream, X, nullptr, nullptr, nullptr, slab, R,
                                C, rpb);
         DTF_CHECK_LAUNCH();
-        hipLaunchKernelGGL(bn_finish_fwd_kernel, dim3((C + 31) / 32), dim3(256), 0, stream, slab, G, C, R, gamma, beta, eps, momentum,
+        hipLaunchKernelGGL(bn_finish_fwd_kernel, dim3((C + BN_FIN_CH - 1) / BN_FIN_CH), dim3(256), 0, stream, slab, G, C, R, gamma, beta, eps, momentum,
                            moving_mean, moving_var, save_mean, save_inv_std, scale, shift);
     } else {
         hipLaunchKernelGGL(bn_infer_coeff_kernel, dim3(cgrid), dim3(256), 0, stream, C, gamma, beta, eps, moving_mean,
@@ -300,7 +303,7 @@ DTF_API int dtf_batchnorm_bwd(const float* X, const float* DY, float* DX, long l
         hipLaunchKernelGGL((bn_partial_kernel<1, true>), dim3(G), dim3(256), 0, stream, X, DY, save_mean, save_inv_std, slab, R, C,
                            rpb);
     DTF_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bn_finish_bwd_kernel, dim3((C + 31) / 32), dim3(256), 0, stream, slab, G, C, R, gamma, save_inv_std,
+    hipLaunchKernelGGL(bn_finish_bwd_kernel, dim3((C + BN_FIN_CH - 1) / BN_FIN_CH), dim3(256), 0, stream, slab, G, C, R, gamma, save_inv_std,
                        dgamma, dbeta, coef);
     DTF_CHECK_LAUNCH();
     if (!DX) return 0;
